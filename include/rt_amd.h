@@ -1,0 +1,239 @@
+/*
+ * rt_amd.h — C ABI of the MI355X (gfx950) path-tracing hot path.
+ *
+ * The reference program (skius/raytracer, one Rust file) exposes no FFI; the seam this library
+ * replaces is the function boundary its hot path already sits behind:
+ *
+ *   Scene::from_objects   src/main.rs:750-774   -> rt_scene_from_objects / rt_scene_create
+ *   Scene::hit            src/main.rs:776-814   -> rt_trace
+ *   render::<W,H>         src/main.rs:977-1039  -> rt_render_accumulate / rt_render_device
+ *   load_obj              src/main.rs:1130-1221 -> rt_mesh_load_obj
+ *   PolygonMesh::rotate_* src/main.rs:627-658   -> rt_mesh_rotate_x/y/z
+ *   PolygonMesh::translate src/main.rs:660-664  -> rt_mesh_translate
+ *   Object::from_mesh     src/main.rs:463-469   -> rt_objects_push_mesh
+ *   Object::sphere        src/main.rs:454-461   -> rt_objects_push_sphere
+ *
+ * Conventions: every function returns RT_OK (0) or a negative RT_ERR_* code and never unwinds
+ * across the boundary; rt_last_error() returns a thread-local message for the last failure.
+ * All pointers are plain host pointers unless the name says "device". A scene may be used from
+ * one host thread at a time. Geometry and shading are computed in IEEE binary64 without fused
+ * multiply-add contraction, in the reference's operation order.
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK 0
+#define RT_ERR_INVALID (-1)   /* bad argument / inconsistent description            */
+#define RT_ERR_NO_DEVICE (-2) /* no HIP device, or the scene is not uploaded        */
+#define RT_ERR_HIP (-3)       /* a HIP runtime call failed                          */
+#define RT_ERR_IO (-4)        /* file could not be read or parsed                   */
+#define RT_ERR_OOM (-5)       /* host or device allocation failed                   */
+
+/* Material kinds — enum Material, src/main.rs:414-425. */
+#define RT_MAT_OPAQUE 0
+#define RT_MAT_DIELECTRIC 1
+
+/* Object kinds — enum Object, src/main.rs:444-448. */
+#define RT_OBJ_MESH 0
+#define RT_OBJ_SPHERE 1
+
+/* rt_render_params.flags */
+#define RT_FLAG_NO_JITTER 1u  /* pixel-centre rays: x_offset = y_offset = 0 (parity checks) */
+#define RT_FLAG_TIMING 2u     /* bracket the path kernel with HIP events                    */
+#define RT_FLAG_COUNT_WORK 4u /* run the counting variant: node visits, triangle tests      */
+#define RT_FLAG_NO_REGEN 8u   /* one thread per path, no path regeneration (A/B baseline)   */
+
+/* One per object, indexed by object index. Material::Opaque / Material::Dielectric,
+ * src/main.rs:414-425; ColorKind src/main.rs:386-390; NormalKind src/main.rs:335-339. */
+typedef struct rt_material {
+  int32_t kind;       /* RT_MAT_*                                              */
+  int32_t color_tex;  /* texture id, or -1 for SolidColor(color)               */
+  int32_t normal_tex; /* texture id of the normal map, or -1 for SimpleNormal  */
+  int32_t reserved;
+  double metallic;
+  double diffuse;
+  double how_metallic;
+  double emission[3];
+  double color[3];    /* SolidColor                                            */
+  double ior;         /* Dielectric(index_of_refraction)                       */
+} rt_material;
+
+/* Decoded texture, 8-bit RGBA, row 0 at the top (what image::DynamicImage::get_pixel sees,
+ * src/main.rs:353, 402). The library copies the pixels. */
+typedef struct rt_texture {
+  const uint8_t* rgba;
+  uint32_t width;
+  uint32_t height;
+} rt_texture;
+
+/* Flat scene description: what Scene::from_objects (src/main.rs:750-774) produces, with the
+ * per-triangle HashMap lookups of src/main.rs:481-483 and 526-529 already resolved into
+ * per-corner arrays. Triangles are in the reference's flat order (object order, then triangle
+ * order); that order defines tie-breaking between equal hit distances (src/main.rs:791). */
+typedef struct rt_scene_desc {
+  uint32_t n_objects;
+  const int32_t* object_kind;     /* [n_objects] RT_OBJ_*                                   */
+  const rt_material* materials;   /* [n_objects]                                            */
+  uint64_t n_triangles;
+  const double* tri_vertices;     /* [n_triangles][3][3]  FlatTriangle.vertices             */
+  const double* tri_normals;      /* [n_triangles][3][3]  vertex normals per corner         */
+  const double* tri_uvs;          /* [n_triangles][3][2]  texture coordinates per corner    */
+  const int32_t* tri_obj;         /* [n_triangles]        FlatTriangle.obj_idx              */
+  const int32_t* tri_idx;         /* [n_triangles]        FlatTriangle.triangle_idx         */
+  uint32_t n_spheres;
+  const double* spheres;          /* [n_spheres][4]  centre xyz, radius                     */
+  const int32_t* sphere_obj;      /* [n_spheres]     object index, ascending                */
+  uint32_t n_textures;
+  const rt_texture* textures;     /* [n_textures]                                           */
+} rt_scene_desc;
+
+/* enum Hit, src/main.rs:668-681. obj = -1 means no hit (None); tri = -1 means Hit::Sphere. */
+typedef struct rt_hit {
+  double t;
+  double u;
+  double v;
+  int32_t obj;
+  int32_t tri;
+} rt_hit;
+
+/* The constants of src/main.rs:1041-1052 and the camera of src/main.rs:978-1013 as run-time
+ * parameters. The defaults of the reference are: 1600x1200, spp 10, max_depth 200,
+ * fov_y_deg 60, dof_strength 0. */
+typedef struct rt_render_params {
+  uint32_t width;
+  uint32_t height;
+  uint32_t spp;          /* NUM_SAMPLES_PER_PIXEL of this call                              */
+  uint32_t first_sample; /* index of this call's first sample in the pixel's sample stream  */
+  uint64_t seed;         /* key of the counter-based generator                              */
+  int32_t max_depth;     /* MAX_DEPTH                                                       */
+  uint32_t flags;        /* RT_FLAG_*                                                       */
+  double fov_y_deg;
+  double dof_strength;   /* DOF_STRENGTH                                                    */
+  uint32_t spp_total;    /* divisor of the per-pixel mean; 0 means spp (src/main.rs:1029)   */
+  uint32_t tile_size;    /* 0: whole image. Otherwise square tiles of this many pixels ...  */
+  uint32_t tile_rank;    /* ... of which this call renders those with index % tile_ranks    */
+  uint32_t tile_ranks;   /*     == tile_rank (row-major tile index)                         */
+} rt_render_params;
+
+typedef struct rt_scene_info {
+  uint64_t n_triangles;
+  uint32_t n_spheres;
+  uint32_t n_objects;
+  uint32_t n_textures;
+  uint32_t bvh_nodes;   /* interior nodes, 64 B each           */
+  uint32_t bvh_leaves;
+  uint32_t bvh_depth;   /* longest root-to-leaf path, in nodes */
+  uint32_t uploaded;    /* device index + 1, or 0              */
+  uint64_t device_bytes;
+} rt_scene_info;
+
+/* Work counters of the last render / trace call made with RT_FLAG_COUNT_WORK (rays is
+ * always maintained). rays counts calls of the nearest-hit query, primary and secondary. */
+typedef struct rt_stats {
+  uint64_t rays;
+  uint64_t node_visits;   /* interior nodes fetched (two child boxes each) */
+  uint64_t tri_tests;     /* ray/triangle tests                            */
+  uint64_t sphere_tests;
+  uint64_t shaded_hits;   /* hits whose shading record was fetched         */
+  uint64_t paths;
+} rt_stats;
+
+/* Durations of the last call made with RT_FLAG_TIMING, measured with HIP events on the
+ * stream the kernels ran on. */
+typedef struct rt_timing {
+  float ms_paths;    /* sum over launches of the path (trace + shade) kernel */
+  float ms_resolve;  /* sum over launches of the sample-resolve kernel       */
+  uint32_t path_launches;
+  uint32_t resolve_launches;
+} rt_timing;
+
+typedef struct rt_mesh rt_mesh;       /* PolygonMesh, src/main.rs:566-574 */
+typedef struct rt_objects rt_objects; /* Vec<Object> being assembled      */
+typedef struct rt_scene rt_scene;     /* Scene, src/main.rs:747           */
+
+/* ---- host side: meshes and scene assembly (no GPU needed) ------------------------------ */
+
+/* load_obj, src/main.rs:1130-1221: "v", "vt", "f" lines; vertex normals are synthesised from
+ * face normals, "vn" lines are ignored. */
+int rt_mesh_load_obj(const char* path, rt_mesh** out);
+int rt_mesh_clone(const rt_mesh* mesh, rt_mesh** out);
+void rt_mesh_destroy(rt_mesh* mesh);
+int rt_mesh_counts(const rt_mesh* mesh, uint64_t* n_vertices, uint64_t* n_triangles, uint64_t* n_uvs);
+/* PolygonMesh::rotate_x/y/z, src/main.rs:627-658 (vertices and vertex normals). */
+int rt_mesh_rotate_x(rt_mesh* mesh, double angle);
+int rt_mesh_rotate_y(rt_mesh* mesh, double angle);
+int rt_mesh_rotate_z(rt_mesh* mesh, double angle);
+/* PolygonMesh::translate, src/main.rs:660-664 (vertices only). */
+int rt_mesh_translate(rt_mesh* mesh, const double t[3]);
+
+int rt_objects_create(rt_objects** out);
+void rt_objects_destroy(rt_objects* objs);
+/* Registers a decoded texture; returns its id (>= 0) or a negative error. */
+int rt_objects_add_texture(rt_objects* objs, const uint8_t* rgba, uint32_t width, uint32_t height);
+/* Object::from_mesh, src/main.rs:463-469. Returns the object index or a negative error. */
+int rt_objects_push_mesh(rt_objects* objs, const rt_mesh* mesh, const rt_material* mat);
+/* Object::sphere, src/main.rs:454-461. Returns the object index or a negative error. */
+int rt_objects_push_sphere(rt_objects* objs, const double centre[3], double radius, const rt_material* mat);
+
+/* Scene::from_objects, src/main.rs:750-774: flattens meshes in object order and builds the
+ * acceleration structure (replaces BVH::build of crate bvh 0.6.0, src/main.rs:771). */
+int rt_scene_from_objects(const rt_objects* objs, rt_scene** out);
+/* Same, from an already flat description. All inputs are copied. */
+int rt_scene_create(const rt_scene_desc* desc, rt_scene** out);
+void rt_scene_destroy(rt_scene* scene);
+int rt_scene_get_info(const rt_scene* scene, rt_scene_info* out);
+/* Copies the flat triangle arrays out (any pointer may be NULL). Layouts as in rt_scene_desc. */
+int rt_scene_export_flat(const rt_scene* scene, double* tri_vertices, double* tri_normals,
+                         double* tri_uvs, int32_t* tri_obj, int32_t* tri_idx);
+/* Copies the acceleration structure out: nodes as bvh_nodes x 16 32-bit words (layout in
+ * raytracer_amd/csrc/rt_types.h), and for each triangle slot in leaf order its flat index. */
+int rt_scene_export_bvh(const rt_scene* scene, uint32_t* node_words, int32_t* leaf_order);
+
+/* ---- device side ------------------------------------------------------------------------ */
+
+int rt_device_count(void);
+/* Copies the scene into the HBM of `device` (idempotent for the same device). */
+int rt_scene_upload(rt_scene* scene, int device);
+
+/* Batch Scene::hit, src/main.rs:776-814. org3/dir3 are [n][3]; dir need not be unit length. */
+int rt_trace(rt_scene* scene, const double* org3, const double* dir3, size_t n, rt_hit* out);
+
+/* Nearest hit of the pixel-centre camera ray of every pixel (render's ray set-up,
+ * src/main.rs:999-1013, with x_offset = y_offset = 0). Outputs are [height][width]. */
+int rt_primary_hits(rt_scene* scene, const rt_render_params* p, int32_t* obj, int32_t* tri,
+                    double* t, double* u, double* v);
+
+/* render::<W,H>, src/main.rs:977-1039: canvas[v][u][c] += mean over p->spp samples.
+ * canvas is a host buffer [height][width][3]. rays_out (may be NULL) receives the number of
+ * nearest-hit queries. */
+int rt_render_accumulate(rt_scene* scene, const rt_render_params* p, double* canvas, uint64_t* rays_out);
+
+/* Same with the canvas in device memory and the work queued on `stream` (a hipStream_t, NULL
+ * for the default stream); returns without waiting. */
+int rt_render_device(rt_scene* scene, const rt_render_params* p, double* device_canvas, void* stream);
+
+/* Sample-split rendering for several GPUs: device_sum[v][u][c] += sum (not mean) of this
+ * call's samples, as binary32 — the buffer a sum-reduction over ranks then combines. */
+int rt_render_sum_f32_device(rt_scene* scene, const rt_render_params* p, float* device_sum, void* stream);
+
+/* Waits for the scene's queued work, then reports. */
+int rt_scene_last_stats(rt_scene* scene, rt_stats* out);
+int rt_scene_last_timing(rt_scene* scene, rt_timing* out);
+
+/* impl Into<Rgba<u8>> for RGBA, src/main.rs:29-37, applied to canvas / its as the display loop
+ * does at src/main.rs:1106-1112. Host buffers; out is [height][width][4]. */
+int rt_quantize_rgba8(const double* canvas, uint32_t width, uint32_t height, uint32_t its, uint8_t* out);
+
+const char* rt_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_H */

@@ -1,0 +1,810 @@
+// rt_host.cpp — host half of the library: OBJ loading, mesh transforms, object list,
+// flattening (Scene::from_objects, src/main.rs:750-774) and the acceleration-structure builder
+// that replaces BVH::build of crate bvh 0.6.0 (src/main.rs:771). No GPU is needed for anything
+// in this file. Compile with -ffp-contract=off: flattened coordinates must carry the same bits
+// the reference's binary64 arithmetic produces.
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rt_types.h"
+
+// ------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+void rt_set_error(const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+}
+
+extern "C" const char* rt_last_error(void) { return g_last_error.c_str(); }
+
+// ------------------------------------------------------------------------------------------
+// meshes — PolygonMesh, src/main.rs:566-574
+// ------------------------------------------------------------------------------------------
+struct D3 {
+  double x, y, z;
+};
+static inline D3 sub(D3 a, D3 b) { return D3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+static inline D3 add(D3 a, D3 b) { return D3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+static inline D3 crs(D3 a, D3 b) { return D3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+static inline D3 unit(D3 a) {
+  double l = std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z);
+  return D3{a.x / l, a.y / l, a.z / l};
+}
+
+struct rt_mesh {
+  std::vector<D3> vertices;
+  std::vector<D3> vertex_normals;
+  std::vector<double> uvs;          // pairs
+  std::vector<uint64_t> tri_vertex; // triples of vertex indices
+  std::vector<uint64_t> tri_uv;     // triples of uv indices (the HashMap of src/main.rs:573)
+};
+
+// One whitespace-separated token list per line, as str::split_whitespace gives.
+static void split_ws(const char* s, size_t n, std::vector<std::string>& out) {
+  out.clear();
+  size_t i = 0;
+  while (i < n) {
+    while (i < n && (s[i] == ' ' || s[i] == '\t' || s[i] == '\r' || s[i] == '\f' || s[i] == '\v')) ++i;
+    size_t b = i;
+    while (i < n && !(s[i] == ' ' || s[i] == '\t' || s[i] == '\r' || s[i] == '\f' || s[i] == '\v')) ++i;
+    if (i > b) out.emplace_back(s + b, i - b);
+  }
+}
+
+static bool parse_f64(const std::string& t, double* v) {
+  char* end = nullptr;
+  *v = std::strtod(t.c_str(), &end);
+  return end && *end == '\0' && end != t.c_str();
+}
+
+// "12", "12/5", "12/5/7" -> the integers between the slashes.
+static bool parse_face_item(const std::string& t, std::vector<uint64_t>& out) {
+  out.clear();
+  size_t b = 0;
+  for (;;) {
+    size_t e = t.find('/', b);
+    std::string piece = t.substr(b, e == std::string::npos ? std::string::npos : e - b);
+    if (piece.empty()) return false;
+    char* end = nullptr;
+    unsigned long long v = std::strtoull(piece.c_str(), &end, 10);
+    if (!end || *end != '\0') return false;
+    out.push_back((uint64_t)v);
+    if (e == std::string::npos) break;
+    b = e + 1;
+  }
+  return true;
+}
+
+extern "C" int rt_mesh_load_obj(const char* path, rt_mesh** out) {
+  if (!path || !out) {
+    rt_set_error("rt_mesh_load_obj: null argument");
+    return RT_ERR_INVALID;
+  }
+  FILE* f = std::fopen(path, "rb");
+  if (!f) {
+    rt_set_error("rt_mesh_load_obj: cannot open %s", path);
+    return RT_ERR_IO;
+  }
+  std::string content;
+  char buf[1 << 16];
+  size_t got;
+  while ((got = std::fread(buf, 1, sizeof buf, f)) > 0) content.append(buf, got);
+  std::fclose(f);
+
+  std::unique_ptr<rt_mesh> m(new (std::nothrow) rt_mesh());
+  if (!m) return RT_ERR_OOM;
+  std::vector<std::string> parts;
+  std::vector<uint64_t> fi[3];
+  size_t pos = 0, line_no = 0;
+  while (pos < content.size()) {
+    size_t nl = content.find('\n', pos);
+    size_t len = (nl == std::string::npos ? content.size() : nl) - pos;
+    split_ws(content.data() + pos, len, parts);
+    pos += len + 1;
+    ++line_no;
+    if (parts.empty()) continue;
+    const std::string& tag = parts[0];
+    if (tag == "v") {  // src/main.rs:1146-1149
+      D3 v;
+      if (parts.size() < 4 || !parse_f64(parts[1], &v.x) || !parse_f64(parts[2], &v.y) || !parse_f64(parts[3], &v.z)) {
+        rt_set_error("%s:%zu: bad vertex line", path, line_no);
+        return RT_ERR_IO;
+      }
+      m->vertices.push_back(v);
+    } else if (tag == "vt") {  // src/main.rs:1181-1184
+      double a, b;
+      if (parts.size() < 3 || !parse_f64(parts[1], &a) || !parse_f64(parts[2], &b)) {
+        rt_set_error("%s:%zu: bad texture-coordinate line", path, line_no);
+        return RT_ERR_IO;
+      }
+      m->uvs.push_back(a);
+      m->uvs.push_back(b);
+    } else if (tag == "f") {  // src/main.rs:1150-1180: first three corners only
+      if (parts.size() < 4) {
+        rt_set_error("%s:%zu: face with fewer than 3 corners", path, line_no);
+        return RT_ERR_IO;
+      }
+      for (int k = 0; k < 3; ++k)
+        if (!parse_face_item(parts[1 + k], fi[k]) || fi[k][0] == 0) {
+          rt_set_error("%s:%zu: bad face corner '%s'", path, line_no, parts[1 + k].c_str());
+          return RT_ERR_IO;
+        }
+      bool has_uv = fi[0].size() >= 2;  // src/main.rs:1156
+      for (int k = 0; k < 3; ++k) {
+        m->tri_vertex.push_back(fi[k][0] - 1);
+        if (has_uv) {
+          if (fi[k].size() < 2 || fi[k][1] == 0) {
+            rt_set_error("%s:%zu: face corner without texture index", path, line_no);
+            return RT_ERR_IO;
+          }
+          m->tri_uv.push_back(fi[k][1] - 1);
+        } else {
+          m->tri_uv.push_back(0);
+        }
+      }
+    }
+  }
+  // src/main.rs:1189 — the coordinate uv-less faces and spheres resolve to
+  m->uvs.push_back(0.0);
+  m->uvs.push_back(1.0);
+
+  const size_t nv = m->vertices.size(), nt = m->tri_vertex.size() / 3, nuv = m->uvs.size() / 2;
+  for (size_t i = 0; i < nt * 3; ++i) {
+    if (m->tri_vertex[i] >= nv || m->tri_uv[i] >= nuv) {
+      rt_set_error("%s: face index out of range", path);
+      return RT_ERR_IO;
+    }
+  }
+  // src/main.rs:1191-1212: vertex normal = normalised sum of the (normalised) normals of the
+  // faces that use the vertex, added in face order.
+  std::vector<D3> sum(nv, D3{0.0, 0.0, 0.0});
+  for (size_t t = 0; t < nt; ++t) {
+    uint64_t i1 = m->tri_vertex[t * 3], i2 = m->tri_vertex[t * 3 + 1], i3 = m->tri_vertex[t * 3 + 2];
+    D3 n = unit(crs(sub(m->vertices[i2], m->vertices[i1]), sub(m->vertices[i3], m->vertices[i1])));
+    sum[i1] = add(sum[i1], n);
+    sum[i2] = add(sum[i2], n);
+    sum[i3] = add(sum[i3], n);
+  }
+  m->vertex_normals.resize(nv);
+  for (size_t i = 0; i < nv; ++i) m->vertex_normals[i] = unit(sum[i]);
+  *out = m.release();
+  return RT_OK;
+}
+
+extern "C" int rt_mesh_clone(const rt_mesh* mesh, rt_mesh** out) {
+  if (!mesh || !out) {
+    rt_set_error("rt_mesh_clone: null argument");
+    return RT_ERR_INVALID;
+  }
+  rt_mesh* c = new (std::nothrow) rt_mesh(*mesh);
+  if (!c) return RT_ERR_OOM;
+  *out = c;
+  return RT_OK;
+}
+
+extern "C" void rt_mesh_destroy(rt_mesh* mesh) { delete mesh; }
+
+extern "C" int rt_mesh_counts(const rt_mesh* mesh, uint64_t* nv, uint64_t* nt, uint64_t* nuv) {
+  if (!mesh) {
+    rt_set_error("rt_mesh_counts: null mesh");
+    return RT_ERR_INVALID;
+  }
+  if (nv) *nv = mesh->vertices.size();
+  if (nt) *nt = mesh->tri_vertex.size() / 3;
+  if (nuv) *nuv = mesh->uvs.size() / 2;
+  return RT_OK;
+}
+
+// Mat3H * Vec3H followed by the homogeneous divide (src/main.rs:156-167, 116-118, 631): every
+// row is a four-term sum against (x, y, z, 1), then divided by the w row's value.
+static inline D3 apply_rows(const double r[4][4], D3 p) {
+  double o[4];
+  for (int i = 0; i < 4; ++i) o[i] = r[i][0] * p.x + r[i][1] * p.y + r[i][2] * p.z + r[i][3] * 1.0;
+  return D3{o[0] / o[3], o[1] / o[3], o[2] / o[3]};
+}
+static int rotate(rt_mesh* mesh, const double r[4][4]) {
+  if (!mesh) {
+    rt_set_error("rt_mesh_rotate: null mesh");
+    return RT_ERR_INVALID;
+  }
+  for (D3& v : mesh->vertices) v = apply_rows(r, v);
+  for (D3& n : mesh->vertex_normals) n = apply_rows(r, n);
+  return RT_OK;
+}
+extern "C" int rt_mesh_rotate_x(rt_mesh* mesh, double angle) {  // src/main.rs:144-153, 649-658
+  double c = std::cos(angle), s = std::sin(angle);
+  const double r[4][4] = {{1.0, 0.0, 0.0, 0.0}, {0.0, c, -s, 0.0}, {0.0, s, c, 0.0}, {0.0, 0.0, 0.0, 1.0}};
+  return rotate(mesh, r);
+}
+extern "C" int rt_mesh_rotate_y(rt_mesh* mesh, double angle) {  // src/main.rs:122-131, 627-636
+  double c = std::cos(angle), s = std::sin(angle);
+  const double r[4][4] = {{c, 0.0, s, 0.0}, {0.0, 1.0, 0.0, 0.0}, {-s, 0.0, c, 0.0}, {0.0, 0.0, 0.0, 1.0}};
+  return rotate(mesh, r);
+}
+extern "C" int rt_mesh_rotate_z(rt_mesh* mesh, double angle) {  // src/main.rs:133-142, 638-647
+  double c = std::cos(angle), s = std::sin(angle);
+  const double r[4][4] = {{c, s, 0.0, 0.0}, {-s, c, 0.0, 0.0}, {0.0, 0.0, 1.0, 0.0}, {0.0, 0.0, 0.0, 1.0}};
+  return rotate(mesh, r);
+}
+extern "C" int rt_mesh_translate(rt_mesh* mesh, const double t[3]) {  // src/main.rs:660-664
+  if (!mesh || !t) {
+    rt_set_error("rt_mesh_translate: null argument");
+    return RT_ERR_INVALID;
+  }
+  for (D3& v : mesh->vertices) v = add(v, D3{t[0], t[1], t[2]});
+  return RT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// object list — Vec<Object>, src/main.rs:444-469
+// ------------------------------------------------------------------------------------------
+struct HostObject {
+  int32_t kind;
+  rt_mesh mesh;
+  double centre[3];
+  double radius;
+  rt_material mat;
+};
+struct rt_objects {
+  std::vector<HostObject> items;
+  std::vector<HostTexture> textures;
+};
+
+extern "C" int rt_objects_create(rt_objects** out) {
+  if (!out) {
+    rt_set_error("rt_objects_create: null argument");
+    return RT_ERR_INVALID;
+  }
+  *out = new (std::nothrow) rt_objects();
+  return *out ? RT_OK : RT_ERR_OOM;
+}
+extern "C" void rt_objects_destroy(rt_objects* objs) { delete objs; }
+
+extern "C" int rt_objects_add_texture(rt_objects* objs, const uint8_t* rgba, uint32_t w, uint32_t h) {
+  if (!objs || !rgba || w == 0 || h == 0) {
+    rt_set_error("rt_objects_add_texture: null argument or empty texture");
+    return RT_ERR_INVALID;
+  }
+  HostTexture t;
+  t.w = w;
+  t.h = h;
+  t.rgba.assign(rgba, rgba + (size_t)w * h * 4);
+  objs->textures.push_back(std::move(t));
+  return (int)objs->textures.size() - 1;
+}
+
+static bool material_ok(const rt_material* m, size_t n_textures) {
+  if (!m) return false;
+  if (m->kind != RT_MAT_OPAQUE && m->kind != RT_MAT_DIELECTRIC) return false;
+  if (m->color_tex < -1 || m->normal_tex < -1) return false;
+  if (m->color_tex >= (int64_t)n_textures || m->normal_tex >= (int64_t)n_textures) return false;
+  return true;
+}
+
+extern "C" int rt_objects_push_mesh(rt_objects* objs, const rt_mesh* mesh, const rt_material* mat) {
+  if (!objs || !mesh || !material_ok(mat, objs->textures.size())) {
+    rt_set_error("rt_objects_push_mesh: null argument or invalid material");
+    return RT_ERR_INVALID;
+  }
+  HostObject o;
+  o.kind = RT_OBJ_MESH;
+  o.mesh = *mesh;
+  o.centre[0] = o.centre[1] = o.centre[2] = 0.0;
+  o.radius = 0.0;
+  o.mat = *mat;
+  objs->items.push_back(std::move(o));
+  return (int)objs->items.size() - 1;
+}
+
+extern "C" int rt_objects_push_sphere(rt_objects* objs, const double centre[3], double radius, const rt_material* mat) {
+  if (!objs || !centre || !material_ok(mat, objs->textures.size())) {
+    rt_set_error("rt_objects_push_sphere: null argument or invalid material");
+    return RT_ERR_INVALID;
+  }
+  HostObject o;
+  o.kind = RT_OBJ_SPHERE;
+  o.centre[0] = centre[0];
+  o.centre[1] = centre[1];
+  o.centre[2] = centre[2];
+  o.radius = radius;
+  o.mat = *mat;
+  objs->items.push_back(std::move(o));
+  return (int)objs->items.size() - 1;
+}
+
+// ------------------------------------------------------------------------------------------
+// acceleration structure
+// ------------------------------------------------------------------------------------------
+// Binned surface-area-heuristic build over binary64 bounds. The tree differs from the crate's
+// (one shape per leaf, 6 buckets): here a leaf holds 1..4 triangles and every interior node
+// stores both child boxes, so one 64-byte fetch decides both children. The nearest hit does
+// not depend on the shape of the tree as long as no box ever excludes a point its triangles
+// can be hit at, so the boxes are rounded outward to f32 and padded (see pad_for()).
+namespace {
+
+struct Box {
+  double lo[3], hi[3];
+};
+inline Box box_empty() {
+  const double inf = std::numeric_limits<double>::infinity();
+  return Box{{inf, inf, inf}, {-inf, -inf, -inf}};
+}
+inline void box_grow(Box& b, const Box& o) {
+  for (int k = 0; k < 3; ++k) {
+    b.lo[k] = std::min(b.lo[k], o.lo[k]);
+    b.hi[k] = std::max(b.hi[k], o.hi[k]);
+  }
+}
+inline double box_half_area(const Box& b) {
+  double dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+  if (!(dx >= 0.0) || !(dy >= 0.0) || !(dz >= 0.0)) return 0.0;
+  return dx * dy + dy * dz + dz * dx;
+}
+inline float f32_down(double x) {
+  float f = (float)x;
+  if ((double)f > x) f = std::nextafter(f, -std::numeric_limits<float>::infinity());
+  return f;
+}
+inline float f32_up(double x) {
+  float f = (float)x;
+  if ((double)f < x) f = std::nextafter(f, std::numeric_limits<float>::infinity());
+  return f;
+}
+
+const double COST_NODE = 1.0;  // one 64-byte fetch + two f32 slab tests
+const double COST_TRI = 2.0;   // one 80-byte fetch + binary64 Moller-Trumbore
+const int N_BINS = 16;
+
+struct Builder {
+  const std::vector<Box>& tb;      // per flat triangle
+  const std::vector<double>& cen;  // centroids, 3 per triangle
+  std::vector<int32_t>& idx;       // permutation being built = leaf order
+  std::vector<BvhNode>& nodes;
+  double pad;
+  uint32_t max_depth = 0;
+  uint32_t leaves = 0;
+
+  static int levels_needed(size_t n) {  // interior levels a balanced split of n triangles needs
+    int l = 0;
+    size_t cap = RT_LEAF_MAX;
+    while (cap < n) {
+      cap *= 2;
+      ++l;
+    }
+    return l;
+  }
+
+  void store_child(BvhNode& n, int c, const Box& b, int32_t ref) {
+    n.bx[c * 2 + 0] = f32_down(b.lo[0] - pad);
+    n.bx[c * 2 + 1] = f32_up(b.hi[0] + pad);
+    n.by[c * 2 + 0] = f32_down(b.lo[1] - pad);
+    n.by[c * 2 + 1] = f32_up(b.hi[1] + pad);
+    n.bz[c * 2 + 0] = f32_down(b.lo[2] - pad);
+    n.bz[c * 2 + 1] = f32_up(b.hi[2] + pad);
+    n.child[c] = ref;
+  }
+
+  // Builds [lo,hi) and returns its ref; depth = interior nodes above this subtree.
+  int32_t build(size_t lo, size_t hi, uint32_t depth, Box* out_box) {
+    const size_t n = hi - lo;
+    Box bounds = box_empty(), cb = box_empty();
+    for (size_t i = lo; i < hi; ++i) {
+      const int32_t t = idx[i];
+      box_grow(bounds, tb[t]);
+      for (int k = 0; k < 3; ++k) {
+        cb.lo[k] = std::min(cb.lo[k], cen[(size_t)t * 3 + k]);
+        cb.hi[k] = std::max(cb.hi[k], cen[(size_t)t * 3 + k]);
+      }
+    }
+    *out_box = bounds;
+
+    // choose a split
+    size_t mid = 0;
+    bool split = false;
+    const bool must_balance = depth + (uint32_t)levels_needed(n) + 1 >= RT_BVH_MAX_DEPTH;
+    if (n > 1 && !must_balance) {
+      double best_cost = std::numeric_limits<double>::infinity();
+      int best_axis = -1, best_bin = -1;
+      for (int axis = 0; axis < 3; ++axis) {
+        const double c0 = cb.lo[axis], ext = cb.hi[axis] - cb.lo[axis];
+        if (!(ext > 0.0) || !std::isfinite(ext)) continue;
+        Box bb[N_BINS];
+        size_t cnt[N_BINS];
+        for (int b = 0; b < N_BINS; ++b) {
+          bb[b] = box_empty();
+          cnt[b] = 0;
+        }
+        const double scale = (double)N_BINS / ext;
+        for (size_t i = lo; i < hi; ++i) {
+          const int32_t t = idx[i];
+          int b = (int)((cen[(size_t)t * 3 + axis] - c0) * scale);
+          b = std::min(std::max(b, 0), N_BINS - 1);
+          cnt[b]++;
+          box_grow(bb[b], tb[t]);
+        }
+        double right_area[N_BINS];
+        size_t right_cnt[N_BINS];
+        Box acc = box_empty();
+        size_t c = 0;
+        for (int b = N_BINS - 1; b > 0; --b) {
+          box_grow(acc, bb[b]);
+          c += cnt[b];
+          right_area[b] = box_half_area(acc);
+          right_cnt[b] = c;
+        }
+        acc = box_empty();
+        c = 0;
+        for (int b = 0; b < N_BINS - 1; ++b) {
+          box_grow(acc, bb[b]);
+          c += cnt[b];
+          if (c == 0 || right_cnt[b + 1] == 0) continue;
+          double cost = box_half_area(acc) * (double)c + right_area[b + 1] * (double)right_cnt[b + 1];
+          if (cost < best_cost) {
+            best_cost = cost;
+            best_axis = axis;
+            best_bin = b;
+          }
+        }
+      }
+      if (best_axis >= 0) {
+        const double area = box_half_area(bounds);
+        const double split_cost = COST_NODE + (area > 0.0 ? best_cost / area : (double)n) * COST_TRI;
+        if (n > RT_LEAF_MAX || split_cost < (double)n * COST_TRI) {
+          const double c0 = cb.lo[best_axis], scale = (double)N_BINS / (cb.hi[best_axis] - cb.lo[best_axis]);
+          auto it = std::stable_partition(idx.begin() + lo, idx.begin() + hi, [&](int32_t t) {
+            int b = (int)((cen[(size_t)t * 3 + best_axis] - c0) * scale);
+            b = std::min(std::max(b, 0), N_BINS - 1);
+            return b <= best_bin;
+          });
+          mid = (size_t)(it - idx.begin());
+          split = mid > lo && mid < hi;
+        }
+      }
+    }
+    if (!split && n > RT_LEAF_MAX) {
+      // coincident centroids, non-finite data, or the depth budget: halve by centroid order
+      int axis = 0;
+      for (int k = 1; k < 3; ++k)
+        if (cb.hi[k] - cb.lo[k] > cb.hi[axis] - cb.lo[axis]) axis = k;
+      mid = lo + n / 2;
+      std::nth_element(idx.begin() + lo, idx.begin() + mid, idx.begin() + hi, [&](int32_t a, int32_t b) {
+        double ca = cen[(size_t)a * 3 + axis], cbv = cen[(size_t)b * 3 + axis];
+        return ca < cbv || (ca == cbv && a < b);
+      });
+      split = true;
+    }
+    if (!split) {
+      std::sort(idx.begin() + lo, idx.begin() + hi);  // flat order inside a leaf
+      leaves++;
+      max_depth = std::max(max_depth, depth);
+      return ~(int32_t)(lo * 4 + (n - 1));
+    }
+    const int32_t me = (int32_t)nodes.size();
+    nodes.emplace_back();
+    std::memset(&nodes[me], 0, sizeof(BvhNode));
+    Box lb, rb;
+    int32_t l = build(lo, mid, depth + 1, &lb);
+    int32_t r = build(mid, hi, depth + 1, &rb);
+    store_child(nodes[me], 0, lb, l);
+    store_child(nodes[me], 1, rb, r);
+    return me;
+  }
+};
+
+int build_scene_accel(rt_scene* s) {
+  const size_t n = s->tri_obj.size();
+  s->nodes.clear();
+  s->leaf_order.clear();
+  s->tri_geom.clear();
+  s->tri_shade.clear();
+  s->root_ref = RT_REF_SENTINEL;
+  s->bvh_depth = 0;
+  s->bvh_leaves = 0;
+  if (n == 0) return RT_OK;
+
+  std::vector<Box> tb(n);
+  std::vector<double> cen(n * 3);
+  double extent = 1.0;
+  for (size_t t = 0; t < n; ++t) {
+    Box b = box_empty();
+    for (int k = 0; k < 3; ++k)
+      for (int c = 0; c < 3; ++c) {
+        double x = s->tri_vertices[t * 9 + k * 3 + c];
+        b.lo[c] = std::min(b.lo[c], x);
+        b.hi[c] = std::max(b.hi[c], x);
+        if (std::isfinite(x)) extent = std::max(extent, std::fabs(x));
+      }
+    tb[t] = b;
+    for (int c = 0; c < 3; ++c) cen[t * 3 + c] = 0.5 * b.lo[c] + 0.5 * b.hi[c];
+  }
+  s->leaf_order.resize(n);
+  for (size_t i = 0; i < n; ++i) s->leaf_order[i] = (int32_t)i;
+  // Absolute padding of every child box: 2^-20 of the largest coordinate in the scene. It
+  // covers the rounding slop of the binary64 triangle test (a hit accepted a hair outside
+  // the exact triangle) with five orders of magnitude to spare for well-conditioned hits.
+  const double pad = extent * 9.5367431640625e-07;
+  Builder b{tb, cen, s->leaf_order, s->nodes, pad};
+  s->nodes.reserve(n);
+  Box root_box;
+  s->root_ref = b.build(0, n, 0, &root_box);
+  s->bvh_depth = b.max_depth;
+  s->bvh_leaves = b.leaves;
+
+  s->tri_geom.resize(n);
+  s->tri_shade.resize(n);
+  for (size_t slot = 0; slot < n; ++slot) {
+    const size_t t = (size_t)s->leaf_order[slot];
+    TriGeom& g = s->tri_geom[slot];
+    const double* v = &s->tri_vertices[t * 9];
+    for (int c = 0; c < 3; ++c) {
+      g.a[c] = v[c];
+      g.ab[c] = v[3 + c] - v[c];  // src/main.rs:188
+      g.ac[c] = v[6 + c] - v[c];  // src/main.rs:189
+    }
+    g.flat = (int32_t)t;
+    g.obj = s->tri_obj[t];
+    TriShade& sh = s->tri_shade[slot];
+    for (int k = 0; k < 3; ++k) {
+      for (int c = 0; c < 3; ++c) sh.n[k][c] = s->tri_normals[t * 9 + k * 3 + c];
+      for (int c = 0; c < 2; ++c) sh.uv[k][c] = s->tri_uvs[t * 6 + k * 2 + c];
+    }
+    sh.tri = s->tri_idx[t];
+    sh.obj = s->tri_obj[t];
+  }
+  return RT_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// scenes
+// ------------------------------------------------------------------------------------------
+extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
+  if (!d || !out) {
+    rt_set_error("rt_scene_create: null argument");
+    return RT_ERR_INVALID;
+  }
+  if (d->n_objects == 0 || !d->object_kind || !d->materials) {
+    rt_set_error("rt_scene_create: a scene needs at least one object");
+    return RT_ERR_INVALID;
+  }
+  if (d->n_triangles >= (1ull << 29)) {
+    rt_set_error("rt_scene_create: too many triangles (%llu)", (unsigned long long)d->n_triangles);
+    return RT_ERR_INVALID;
+  }
+  if (d->n_triangles && (!d->tri_vertices || !d->tri_normals || !d->tri_uvs || !d->tri_obj || !d->tri_idx)) {
+    rt_set_error("rt_scene_create: null triangle array");
+    return RT_ERR_INVALID;
+  }
+  if (d->n_spheres && (!d->spheres || !d->sphere_obj)) {
+    rt_set_error("rt_scene_create: null sphere array");
+    return RT_ERR_INVALID;
+  }
+  if (d->n_textures && !d->textures) {
+    rt_set_error("rt_scene_create: null texture array");
+    return RT_ERR_INVALID;
+  }
+  for (uint32_t i = 0; i < d->n_textures; ++i)
+    if (!d->textures[i].rgba || d->textures[i].width == 0 || d->textures[i].height == 0) {
+      rt_set_error("rt_scene_create: texture %u is empty", i);
+      return RT_ERR_INVALID;
+    }
+  for (uint32_t i = 0; i < d->n_objects; ++i) {
+    if (d->object_kind[i] != RT_OBJ_MESH && d->object_kind[i] != RT_OBJ_SPHERE) {
+      rt_set_error("rt_scene_create: object %u has unknown kind %d", i, d->object_kind[i]);
+      return RT_ERR_INVALID;
+    }
+    if (!material_ok(&d->materials[i], d->n_textures)) {
+      rt_set_error("rt_scene_create: object %u has an invalid material", i);
+      return RT_ERR_INVALID;
+    }
+  }
+  for (uint64_t t = 0; t < d->n_triangles; ++t) {
+    int32_t o = d->tri_obj[t];
+    if (o < 0 || (uint32_t)o >= d->n_objects || d->object_kind[o] != RT_OBJ_MESH || d->tri_idx[t] < 0) {
+      rt_set_error("rt_scene_create: triangle %llu names object %d, which is not a mesh", (unsigned long long)t, o);
+      return RT_ERR_INVALID;
+    }
+  }
+  int32_t prev = -1;
+  uint32_t sphere_objects = 0;
+  for (uint32_t i = 0; i < d->n_objects; ++i) sphere_objects += d->object_kind[i] == RT_OBJ_SPHERE;
+  if (sphere_objects != d->n_spheres) {
+    rt_set_error("rt_scene_create: %u sphere objects but %u sphere records", sphere_objects, d->n_spheres);
+    return RT_ERR_INVALID;
+  }
+  for (uint32_t i = 0; i < d->n_spheres; ++i) {
+    int32_t o = d->sphere_obj[i];
+    if (o <= prev || (uint32_t)o >= d->n_objects || d->object_kind[o] != RT_OBJ_SPHERE) {
+      rt_set_error("rt_scene_create: sphere %u names object %d (must be ascending sphere objects)", i, o);
+      return RT_ERR_INVALID;
+    }
+    prev = o;
+  }
+
+  std::unique_ptr<rt_scene> s(new (std::nothrow) rt_scene());
+  if (!s) return RT_ERR_OOM;
+  try {
+    s->object_kind.assign(d->object_kind, d->object_kind + d->n_objects);
+    s->materials.assign(d->materials, d->materials + d->n_objects);
+    const size_t n = (size_t)d->n_triangles;
+    if (n) {
+      s->tri_vertices.assign(d->tri_vertices, d->tri_vertices + n * 9);
+      s->tri_normals.assign(d->tri_normals, d->tri_normals + n * 9);
+      s->tri_uvs.assign(d->tri_uvs, d->tri_uvs + n * 6);
+      s->tri_obj.assign(d->tri_obj, d->tri_obj + n);
+      s->tri_idx.assign(d->tri_idx, d->tri_idx + n);
+    }
+    for (uint32_t i = 0; i < d->n_spheres; ++i) {
+      SphereRec r;
+      std::memset(&r, 0, sizeof r);
+      r.c[0] = d->spheres[i * 4 + 0];
+      r.c[1] = d->spheres[i * 4 + 1];
+      r.c[2] = d->spheres[i * 4 + 2];
+      r.r = d->spheres[i * 4 + 3];
+      r.obj = d->sphere_obj[i];
+      s->spheres.push_back(r);
+    }
+    for (uint32_t i = 0; i < d->n_textures; ++i) {
+      HostTexture t;
+      t.w = d->textures[i].width;
+      t.h = d->textures[i].height;
+      t.rgba.assign(d->textures[i].rgba, d->textures[i].rgba + (size_t)t.w * t.h * 4);
+      s->textures.push_back(std::move(t));
+    }
+    int rc = build_scene_accel(s.get());
+    if (rc != RT_OK) return rc;
+  } catch (const std::bad_alloc&) {
+    rt_set_error("rt_scene_create: out of host memory");
+    return RT_ERR_OOM;
+  }
+  *out = s.release();
+  return RT_OK;
+}
+
+// Scene::from_objects, src/main.rs:750-774: meshes are flattened in object order, then
+// triangle order; the per-corner normals and texture coordinates that normal_at_hit and
+// get_tex_uv_coords would look up (src/main.rs:526-529, 481-483) are gathered here once.
+extern "C" int rt_scene_from_objects(const rt_objects* objs, rt_scene** out) {
+  if (!objs || !out) {
+    rt_set_error("rt_scene_from_objects: null argument");
+    return RT_ERR_INVALID;
+  }
+  try {
+    std::vector<int32_t> kinds;
+    std::vector<rt_material> mats;
+    std::vector<double> tv, tn, tuv, sph;
+    std::vector<int32_t> tobj, tidx, sobj;
+    for (size_t oi = 0; oi < objs->items.size(); ++oi) {
+      const HostObject& o = objs->items[oi];
+      kinds.push_back(o.kind);
+      mats.push_back(o.mat);
+      if (o.kind == RT_OBJ_SPHERE) {
+        sph.insert(sph.end(), {o.centre[0], o.centre[1], o.centre[2], o.radius});
+        sobj.push_back((int32_t)oi);
+        continue;
+      }
+      const rt_mesh& m = o.mesh;
+      const size_t nt = m.tri_vertex.size() / 3;
+      for (size_t t = 0; t < nt; ++t) {
+        for (int k = 0; k < 3; ++k) {
+          const D3& v = m.vertices[m.tri_vertex[t * 3 + k]];
+          const D3& nn = m.vertex_normals[m.tri_vertex[t * 3 + k]];
+          tv.insert(tv.end(), {v.x, v.y, v.z});
+          tn.insert(tn.end(), {nn.x, nn.y, nn.z});
+          const uint64_t ui = m.tri_uv[t * 3 + k];
+          tuv.insert(tuv.end(), {m.uvs[ui * 2], m.uvs[ui * 2 + 1]});
+        }
+        tobj.push_back((int32_t)oi);
+        tidx.push_back((int32_t)t);
+      }
+    }
+    std::vector<rt_texture> tex;
+    for (const HostTexture& t : objs->textures) tex.push_back(rt_texture{t.rgba.data(), t.w, t.h});
+    rt_scene_desc d;
+    std::memset(&d, 0, sizeof d);
+    d.n_objects = (uint32_t)kinds.size();
+    d.object_kind = kinds.data();
+    d.materials = mats.data();
+    d.n_triangles = tobj.size();
+    d.tri_vertices = tv.data();
+    d.tri_normals = tn.data();
+    d.tri_uvs = tuv.data();
+    d.tri_obj = tobj.data();
+    d.tri_idx = tidx.data();
+    d.n_spheres = (uint32_t)sobj.size();
+    d.spheres = sph.data();
+    d.sphere_obj = sobj.data();
+    d.n_textures = (uint32_t)tex.size();
+    d.textures = tex.data();
+    return rt_scene_create(&d, out);
+  } catch (const std::bad_alloc&) {
+    rt_set_error("rt_scene_from_objects: out of host memory");
+    return RT_ERR_OOM;
+  }
+}
+
+extern "C" void rt_scene_destroy(rt_scene* scene) {
+  if (!scene) return;
+  if (scene->dev) rt_device_scene_free(scene->dev);
+  delete scene;
+}
+
+extern "C" int rt_scene_get_info(const rt_scene* s, rt_scene_info* out) {
+  if (!s || !out) {
+    rt_set_error("rt_scene_get_info: null argument");
+    return RT_ERR_INVALID;
+  }
+  std::memset(out, 0, sizeof *out);
+  out->n_triangles = s->tri_obj.size();
+  out->n_spheres = (uint32_t)s->spheres.size();
+  out->n_objects = (uint32_t)s->object_kind.size();
+  out->n_textures = (uint32_t)s->textures.size();
+  out->bvh_nodes = (uint32_t)s->nodes.size();
+  out->bvh_leaves = s->bvh_leaves;
+  out->bvh_depth = s->bvh_depth;
+  if (s->dev) rt_device_scene_info(s->dev, &out->uploaded, &out->device_bytes);
+  return RT_OK;
+}
+
+extern "C" int rt_scene_export_flat(const rt_scene* s, double* tv, double* tn, double* tuv, int32_t* tobj, int32_t* tidx) {
+  if (!s) {
+    rt_set_error("rt_scene_export_flat: null scene");
+    return RT_ERR_INVALID;
+  }
+  const size_t n = s->tri_obj.size();
+  if (n == 0) return RT_OK;
+  if (tv) std::memcpy(tv, s->tri_vertices.data(), n * 9 * sizeof(double));
+  if (tn) std::memcpy(tn, s->tri_normals.data(), n * 9 * sizeof(double));
+  if (tuv) std::memcpy(tuv, s->tri_uvs.data(), n * 6 * sizeof(double));
+  if (tobj) std::memcpy(tobj, s->tri_obj.data(), n * sizeof(int32_t));
+  if (tidx) std::memcpy(tidx, s->tri_idx.data(), n * sizeof(int32_t));
+  return RT_OK;
+}
+
+extern "C" int rt_scene_export_bvh(const rt_scene* s, uint32_t* node_words, int32_t* leaf_order) {
+  if (!s) {
+    rt_set_error("rt_scene_export_bvh: null scene");
+    return RT_ERR_INVALID;
+  }
+  if (node_words && !s->nodes.empty()) std::memcpy(node_words, s->nodes.data(), s->nodes.size() * sizeof(BvhNode));
+  if (leaf_order && !s->leaf_order.empty()) std::memcpy(leaf_order, s->leaf_order.data(), s->leaf_order.size() * sizeof(int32_t));
+  return RT_OK;
+}
+
+// impl Into<Rgba<u8>> for RGBA, src/main.rs:29-37, on canvas / its (src/main.rs:1109).
+extern "C" int rt_quantize_rgba8(const double* canvas, uint32_t w, uint32_t h, uint32_t its, uint8_t* out) {
+  if (!canvas || !out || its == 0) {
+    rt_set_error("rt_quantize_rgba8: null argument or its == 0");
+    return RT_ERR_INVALID;
+  }
+  const double n = (double)its;
+  for (size_t i = 0; i < (size_t)w * h; ++i) {
+    for (int c = 0; c < 3; ++c) {
+      double x = (canvas[i * 3 + c] / n) * 255.0;
+      // f64::clamp(0, 255) then `as u8` (truncation; NaN -> 0)
+      if (x < 0.0) x = 0.0;
+      if (x > 255.0) x = 255.0;
+      out[i * 4 + c] = (x == x) ? (uint8_t)x : 0;
+    }
+    out[i * 4 + 3] = 255;
+  }
+  return RT_OK;
+}

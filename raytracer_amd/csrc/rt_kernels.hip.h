@@ -1,0 +1,480 @@
+// rt_kernels.hip.h — gfx950 device code for the render hot path.
+//
+//   trace_ray     Scene::hit                 src/main.rs:776-814  (+ intersects_triangle 187-239,
+//                                                                     intersects_sphere 241-262)
+//   camera_ray    render's ray set-up        src/main.rs:995-1013
+//   shade_hit     raytrace's hit branch      src/main.rs:829-969  (+ normal_at_hit 515-562,
+//                                             get_tex_uv_coords 471-492, color_at 392-411,
+//                                             normal_at 341-381, refract 320-327, reflectance 329-333)
+//   sky           interp_sky                 src/main.rs:302-312
+//
+// Arithmetic contract: every value that decides where a ray goes (hit tests, normals, scatter
+// directions, texture addresses) is computed in binary64 with the reference's operation order
+// and without fused multiply-add (this file must be compiled with -ffp-contract=off; the only
+// fused operations are the explicit __builtin_fma calls in pow6, which feed colour only).
+// The f32 arithmetic is confined to box culling, which is conservative by construction.
+#ifndef RT_KERNELS_HIP_H
+#define RT_KERNELS_HIP_H
+
+#include <hip/hip_runtime.h>
+
+#include "rt_types.h"
+
+#define RT_WAVE 64
+#define RT_BLOCK 256
+
+namespace rtk {
+
+struct d3 {
+  double x, y, z;
+};
+__device__ __forceinline__ d3 mk(double x, double y, double z) { return d3{x, y, z}; }
+__device__ __forceinline__ d3 operator-(d3 a, d3 b) { return d3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ d3 operator+(d3 a, d3 b) { return d3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ d3 operator*(double s, d3 r) { return d3{s * r.x, s * r.y, s * r.z}; }
+// src/main.rs:69-71: (a0*b0 + a1*b1) + a2*b2
+__device__ __forceinline__ double dot(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ double length(d3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+__device__ __forceinline__ d3 cross(d3 a, d3 b) {
+  return d3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ d3 normalize(d3 a) {
+  double l = length(a);
+  return d3{a.x / l, a.y / l, a.z / l};
+}
+
+// ------------------------------------------------------------------------------------------
+// counter-based generator: draw = mix64(key + GOLDEN * ((stage << 20) + index + 1)), 53 bits
+// ------------------------------------------------------------------------------------------
+#define RT_GOLDEN 0x9e3779b97f4a7c15ull
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z ^= z >> 30;
+  z *= 0xbf58476d1ce4e5b9ull;
+  z ^= z >> 27;
+  z *= 0x94d049bb133111ebull;
+  z ^= z >> 31;
+  return z;
+}
+__device__ __forceinline__ uint64_t path_key(uint64_t seed, uint64_t pixel, uint64_t sample) {
+  uint64_t k = mix64(seed + RT_GOLDEN);
+  k = mix64(k + RT_GOLDEN * (pixel + 1));
+  k = mix64(k + RT_GOLDEN * (sample + 1));
+  return k;
+}
+struct Rng {
+  uint64_t x;  // key + GOLDEN * ((stage << 20) + index): advanced by GOLDEN per draw
+  __device__ __forceinline__ void start(uint64_t key, uint32_t stage) { x = key + RT_GOLDEN * ((uint64_t)stage << 20); }
+  __device__ __forceinline__ double u01() {
+    x += RT_GOLDEN;
+    return (double)(mix64(x) >> 11) * (1.0 / 9007199254740992.0);
+  }
+  __device__ __forceinline__ double range(double lo, double hi) { return lo + (hi - lo) * u01(); }
+  __device__ __forceinline__ void skip(uint32_t n) { x += RT_GOLDEN * (uint64_t)n; }
+};
+
+// random_unit_sphere_surface, src/main.rs:264-279 (Marsaglia), capped at RT_REJECT_CAP tries.
+__device__ __forceinline__ d3 random_unit_sphere_surface(Rng& r) {
+  for (int tries = 0; tries < RT_REJECT_CAP; ++tries) {
+    double x1 = r.range(-1.0, 1.0);
+    double x2 = r.range(-1.0, 1.0);
+    if (x1 * x1 + x2 * x2 >= 1.0) continue;
+    double sq = sqrt(1.0 - x1 * x1 - x2 * x2);
+    double x = 2.0 * x1 * sq;
+    double y = 2.0 * x2 * sq;
+    double z = 1.0 - 2.0 * (x1 * x1 + x2 * x2);
+    return mk(x, y, z);
+  }
+  return mk(0.0, 0.0, 1.0);
+}
+
+// ------------------------------------------------------------------------------------------
+// scene view handed to kernels by value
+// ------------------------------------------------------------------------------------------
+struct SceneK {
+  const BvhNode* nodes;
+  const TriGeom* geom;
+  const TriShade* shade;
+  const SphereRec* spheres;
+  const rt_material* mats;
+  const TextureRec* tex;
+  int32_t root_ref;
+  uint32_t n_spheres;
+};
+
+struct HitK {
+  double t, u, v;
+  int32_t slot;    // leaf-order triangle slot, or -1
+  int32_t sphere;  // sphere record index, or -1
+};
+
+struct WorkCount {
+  uint32_t rays, nodes, tris, spheres, shaded;
+};
+
+// ------------------------------------------------------------------------------------------
+// Scene::hit
+// ------------------------------------------------------------------------------------------
+// Box culling in f32 that can only err towards visiting: the ray origin is widened by `pad`
+// (>= its f32 rounding error), the far distance is scaled up by (1 + 2^-20), and the
+// pruning distance is the hit distance rounded up to f32 and scaled the same way; the boxes
+// themselves were rounded outward and padded by the builder.
+#define RT_K_FAR 1.00000095367431640625f /* 1 + 2^-20 */
+
+__device__ __forceinline__ float f32_up(double x) {
+  return __double2float_ru(x);
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void trace_ray(const SceneK& sc, const d3 o, const d3 d, int32_t* stk, const int stride,
+                                          HitK& h, WorkCount& wc) {
+  const double eps = 0.00000001;  // src/main.rs:185
+  double best_t = __longlong_as_double(0x7ff0000000000000ll);
+  double best_u = 0.0, best_v = 0.0;
+  int32_t best_slot = -1, best_flat = 0x7fffffff;
+
+  // culling ray
+  const double omax = fmax(fabs(o.x), fmax(fabs(o.y), fabs(o.z)));
+  const float pad = f32_up(omax * 2.384185791015625e-07);  // 2^-22
+  const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
+  const float ox_lo = ox - pad, ox_hi = ox + pad;
+  const float oy_lo = oy - pad, oy_hi = oy + pad;
+  const float oz_lo = oz - pad, oz_hi = oz + pad;
+  double dx = d.x, dy = d.y, dz = d.z;
+  if (fabs(dx) < 1e-30) dx = signbit(dx) ? -1e-30 : 1e-30;
+  if (fabs(dy) < 1e-30) dy = signbit(dy) ? -1e-30 : 1e-30;
+  if (fabs(dz) < 1e-30) dz = signbit(dz) ? -1e-30 : 1e-30;
+  const float ix = (float)(1.0 / dx), iy = (float)(1.0 / dy), iz = (float)(1.0 / dz);
+  float best32k = __int_as_float(0x7f800000);
+
+  int sp = 0;
+  stk[0] = RT_REF_SENTINEL;
+  int32_t cur = sc.root_ref;
+
+  for (;;) {
+    while (cur >= 0) {
+      const float4* np = reinterpret_cast<const float4*>(sc.nodes + cur);
+      const float4 bx = np[0], by = np[1], bz = np[2];
+      const int4 ch = reinterpret_cast<const int4*>(np)[3];
+      if (COUNT) wc.nodes++;
+      // child 0
+      float ta, tb, tn0, tf0, tn1, tf1;
+      ta = (bx.x - ox_hi) * ix;
+      tb = (bx.y - ox_lo) * ix;
+      tn0 = fminf(ta, tb);
+      tf0 = fmaxf(ta, tb);
+      ta = (by.x - oy_hi) * iy;
+      tb = (by.y - oy_lo) * iy;
+      tn0 = fmaxf(tn0, fminf(ta, tb));
+      tf0 = fminf(tf0, fmaxf(ta, tb));
+      ta = (bz.x - oz_hi) * iz;
+      tb = (bz.y - oz_lo) * iz;
+      tn0 = fmaxf(fmaxf(tn0, fminf(ta, tb)), 0.0f);
+      tf0 = fminf(tf0, fmaxf(ta, tb)) * RT_K_FAR;
+      // child 1
+      ta = (bx.z - ox_hi) * ix;
+      tb = (bx.w - ox_lo) * ix;
+      tn1 = fminf(ta, tb);
+      tf1 = fmaxf(ta, tb);
+      ta = (by.z - oy_hi) * iy;
+      tb = (by.w - oy_lo) * iy;
+      tn1 = fmaxf(tn1, fminf(ta, tb));
+      tf1 = fminf(tf1, fmaxf(ta, tb));
+      ta = (bz.z - oz_hi) * iz;
+      tb = (bz.w - oz_lo) * iz;
+      tn1 = fmaxf(fmaxf(tn1, fminf(ta, tb)), 0.0f);
+      tf1 = fminf(tf1, fmaxf(ta, tb)) * RT_K_FAR;
+
+      const bool h0 = tn0 <= fminf(tf0, best32k);
+      const bool h1 = tn1 <= fminf(tf1, best32k);
+      if (h0 && h1) {
+        const bool swap = tn1 < tn0;
+        const int32_t near = swap ? ch.y : ch.x;
+        const int32_t far = swap ? ch.x : ch.y;
+        sp += 1;
+        stk[sp * stride] = far;
+        cur = near;
+      } else if (h0) {
+        cur = ch.x;
+      } else if (h1) {
+        cur = ch.y;
+      } else {
+        cur = stk[sp * stride];
+        sp -= 1;
+      }
+    }
+    if (cur == RT_REF_SENTINEL) break;
+    // leaf
+    const uint32_t leaf = (uint32_t)~cur;
+    const uint32_t first = leaf >> 2, cnt = (leaf & 3u) + 1u;
+    for (uint32_t i = 0; i < cnt; ++i) {
+      const TriGeom* g = sc.geom + (first + i);
+      const d3 a = mk(g->a[0], g->a[1], g->a[2]);
+      const d3 a_to_b = mk(g->ab[0], g->ab[1], g->ab[2]);
+      const d3 a_to_c = mk(g->ac[0], g->ac[1], g->ac[2]);
+      const int32_t flat = g->flat;
+      if (COUNT) wc.tris++;
+      // intersects_triangle, src/main.rs:187-239
+      const d3 u_vec = cross(d, a_to_c);
+      const double det = dot(a_to_b, u_vec);
+      bool ok = !(det < eps && det > -eps);
+      const double inv_det = 1.0 / det;
+      const d3 a_to_origin = o - a;
+      const double u = dot(a_to_origin, u_vec) * inv_det;
+      ok = ok && (u >= 0.0 && u <= 1.0);
+      const d3 v_vec = cross(a_to_origin, a_to_b);
+      const double v = dot(d, v_vec) * inv_det;
+      ok = ok && !(v < 0.0 || u + v > 1.0);
+      const double dist = dot(a_to_c, v_vec) * inv_det;
+      ok = ok && (dist > eps);
+      // src/main.rs:791: strict <, so of equal distances the first in flat order wins
+      if (ok && (dist < best_t || (dist == best_t && flat < best_flat))) {
+        best_t = dist;
+        best_u = u;
+        best_v = v;
+        best_slot = (int32_t)(first + i);
+        best_flat = flat;
+        best32k = f32_up(dist) * RT_K_FAR;
+      }
+    }
+    cur = stk[sp * stride];
+    sp -= 1;
+  }
+
+  h.t = best_t;
+  h.u = best_u;
+  h.v = best_v;
+  h.slot = best_slot;
+  h.sphere = -1;
+  // src/main.rs:802-810: every sphere, in object order; strictly nearer replaces
+  for (uint32_t i = 0; i < sc.n_spheres; ++i) {
+    const SphereRec* s = sc.spheres + i;
+    if (COUNT) wc.spheres++;
+    // intersects_sphere, src/main.rs:241-262
+    const d3 oc = o - mk(s->c[0], s->c[1], s->c[2]);
+    const double a = dot(d, d);
+    const double half_b = dot(oc, d);
+    const double c = dot(oc, oc) - s->r * s->r;
+    const double discriminant = half_b * half_b - a * c;
+    if (discriminant < 0.0) continue;
+    const double sqrtd = sqrt(discriminant);
+    double root = (-half_b - sqrtd) / a;
+    if (root < eps) {
+      root = (-half_b + sqrtd) / a;
+      if (root < eps) continue;
+    }
+    if (root < h.t) {
+      h.t = root;
+      h.slot = -1;
+      h.sphere = (int32_t)i;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// sky — interp_sky, src/main.rs:302-312
+// ------------------------------------------------------------------------------------------
+// x^6 in double-double arithmetic, rounded once: agrees with a correctly rounded pow(x, 6.0)
+// except when the exact value lies within 2^-100 of a rounding boundary. Colour only.
+__device__ __forceinline__ double pow6(double x) {
+  const double p2 = x * x;
+  const double e2 = __builtin_fma(x, x, -p2);
+  double p3 = p2 * x;
+  double e3 = __builtin_fma(p2, x, -p3) + e2 * x;
+  const double s3 = p3 + e3;
+  e3 = e3 - (s3 - p3);
+  p3 = s3;
+  const double p6 = p3 * p3;
+  const double e6 = __builtin_fma(p3, p3, -p6) + 2.0 * (p3 * e3);
+  return p6 + e6;
+}
+
+__device__ __forceinline__ d3 sky(const d3 dir) {
+  const d3 c1 = mk(0.4, 0.6, 0.8);
+  const d3 c2 = mk(0.8, 0.8, 0.8);
+  const d3 light_c = mk(1.5, 1.5, 1.5);
+  const d3 light_dir = normalize(mk(1.0, 2.0, 1.0));
+  double t = dot(dir, light_dir);
+  t = pow6((t + 1.0) / 2.0);
+  return (1.0 - t) * (dir.y * c2 + (1.0 - dir.y) * c1) + t * light_c;
+}
+
+// ------------------------------------------------------------------------------------------
+// textures
+// ------------------------------------------------------------------------------------------
+// `(x).floor() as u32` saturates (negative and NaN -> 0); image::get_pixel would panic one
+// past the edge (exact u == 1 or v == 0 only), here the address is clamped to the last texel.
+__device__ __forceinline__ uint32_t texel_index(double x, uint32_t n) {
+  const double f = floor(x);
+  uint32_t i = 0;
+  if (f > 0.0) i = f >= 4294967295.0 ? 4294967295u : (uint32_t)f;
+  return i >= n ? n - 1 : i;
+}
+__device__ __forceinline__ uchar4 fetch_texel(const TextureRec& t, double u, double v) {
+  const uint32_t x = texel_index(u * (double)t.w, t.w);
+  const uint32_t y = texel_index((1.0 - v) * (double)t.h, t.h);
+  return *reinterpret_cast<const uchar4*>(t.rgba + ((size_t)y * t.w + x) * 4);
+}
+
+__device__ __forceinline__ double bary(double a, double b, double c, double u, double v) {  // src/main.rs:741-745
+  return (1.0 - u - v) * a + u * b + v * c;
+}
+
+// f64::powi(5): square-and-multiply from the low bit
+__device__ __forceinline__ double powi5(double a) {
+  const double a2 = a * a;
+  const double a4 = a2 * a2;
+  return a * a4;
+}
+
+// ------------------------------------------------------------------------------------------
+// raytrace's hit branch. Returns false when the path ends here (never for a hit: the path
+// continues until a miss or the depth cap), fills the next ray and updates throughput/radiance.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void shade_hit(const SceneK& sc, const HitK& h, const uint64_t key, const int depth, d3& o,
+                                          d3& dir, d3& thr, d3& rad) {
+  const double eps = 0.00000001;
+  const d3 hit_pos = o + h.t * dir;  // src/main.rs:831
+  d3 normal;
+  double tex_u = 0.0, tex_v = 1.0;  // src/main.rs:490
+  int32_t obj;
+  if (h.slot >= 0) {
+    const TriShade* s = sc.shade + h.slot;
+    obj = s->obj;
+    // src/main.rs:526-531 — bary_interp of the vertex normals, not normalised
+    const double w = 1.0 - h.u - h.v;
+    normal = (w * mk(s->n[0][0], s->n[0][1], s->n[0][2]) + h.u * mk(s->n[1][0], s->n[1][1], s->n[1][2])) +
+             h.v * mk(s->n[2][0], s->n[2][1], s->n[2][2]);
+    tex_u = bary(s->uv[0][0], s->uv[1][0], s->uv[2][0], h.u, h.v);  // src/main.rs:485-486
+    tex_v = bary(s->uv[0][1], s->uv[1][1], s->uv[2][1], h.u, h.v);
+  } else {
+    const SphereRec* s = sc.spheres + h.sphere;
+    obj = s->obj;
+    normal = normalize(hit_pos - mk(s->c[0], s->c[1], s->c[2]));  // src/main.rs:556-557
+  }
+  const rt_material* m = sc.mats + obj;
+  const int kind = m->kind;
+  const d3 camera_dir = normalize(-1.0 * dir);  // src/main.rs:835
+  Rng rng;
+  rng.start(key, (uint32_t)depth + 1u);
+
+  if (kind == RT_MAT_OPAQUE) {
+    if (h.slot >= 0 && m->normal_tex >= 0) {
+      // NormalKind::normal_at, src/main.rs:347-378
+      const uchar4 px = fetch_texel(sc.tex[m->normal_tex], tex_u, tex_v);
+      const d3 ts_normal = normalize(mk((double)px.x / 255.0, (double)px.y / 255.0, (double)px.z / 255.0));
+      d3 t = cross(normal, mk(0.0, 1.0, 0.0));
+      if (fabs(length(t)) < eps) t = cross(normal, mk(0.0, 0.0, 1.0));
+      t = normalize(t);
+      const d3 b = cross(normal, t);
+      const d3 map_n = 2.0 * ts_normal - mk(1.0, 1.0, 1.0);
+      // tbn * (map_n, 1) row by row (four-term sums, src/main.rs:160-165), then divide by w
+      const double w4 = 0.0 * map_n.x + 0.0 * map_n.y + 0.0 * map_n.z + 1.0 * 1.0;
+      const d3 nn = mk((t.x * map_n.x + b.x * map_n.y + normal.x * map_n.z + 0.0 * 1.0) / w4,
+                       (t.y * map_n.x + b.y * map_n.y + normal.y * map_n.z + 0.0 * 1.0) / w4,
+                       (t.z * map_n.x + b.z * map_n.y + normal.z * map_n.z + 0.0 * 1.0) / w4);
+      normal = normalize(nn);
+    }
+    // ColorKind::color_at, src/main.rs:392-411
+    d3 point;
+    if (m->color_tex >= 0) {
+      const uchar4 px = fetch_texel(sc.tex[m->color_tex], tex_u, tex_v);
+      point = mk((double)px.x / 255.0, (double)px.y / 255.0, (double)px.z / 255.0);
+    } else {
+      point = mk(m->color[0], m->color[1], m->color[2]);
+    }
+    const double metallic = m->metallic, diffuse = m->diffuse, how_metallic = m->how_metallic;
+    // src/main.rs:851-857
+    const double cdn = dot(camera_dir, normal);
+    d3 r;
+    if (cdn < 0.0) {
+      r = -1.0 * camera_dir;
+    } else {
+      r = 2.0 * cdn * normal - camera_dir;
+    }
+    const d3 reflected_camera = normalize(r);
+    const d3 jit = metallic * random_unit_sphere_surface(rng);  // src/main.rs:869
+    rng.skip(3);                                                // src/main.rs:871-873, unused draws
+    d3 diffuse_out = mk(0.0, 0.0, 0.0);
+    for (int tries = 0; tries < RT_REJECT_CAP; ++tries) {  // src/main.rs:876-883
+      const d3 rs = random_unit_sphere_surface(rng);
+      if (dot(rs, normal) > 0.0) {
+        diffuse_out = rs;
+        break;
+      }
+    }
+    diffuse_out = diffuse * diffuse_out + normal;  // src/main.rs:884
+    if (length(diffuse_out) < eps) {
+      diffuse_out = normal;
+    } else {
+      diffuse_out = normalize(diffuse_out);
+    }
+    const d3 fuzzy_out = normalize(jit + reflected_camera);                              // src/main.rs:896
+    const d3 out_dir = how_metallic * fuzzy_out + (1.0 - how_metallic) * diffuse_out;  // src/main.rs:900
+    o = hit_pos + eps * out_dir;                                                        // src/main.rs:903
+    dir = out_dir;
+    // src/main.rs:925-929 unrolled: L = albedo * (L_in + emission)
+    thr = mk(thr.x * point.x, thr.y * point.y, thr.z * point.z);
+    rad = rad + mk(thr.x * m->emission[0], thr.y * m->emission[1], thr.z * m->emission[2]);
+  } else {
+    // Dielectric, src/main.rs:936-969
+    const double ior = m->ior;
+    const bool front_face = dot(normal, camera_dir) > 0.0;
+    const d3 n = front_face ? normal : -1.0 * normal;
+    const double eta = front_face ? 1.0 / ior : ior;
+    const double cos_theta = fmin(dot(camera_dir, n), 1.0);
+    const double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+    const bool cannot_refract = eta * sin_theta > 1.0;
+    // reflectance, src/main.rs:329-333
+    double r0 = (1.0 - eta) / (1.0 + eta);
+    r0 = r0 * r0;
+    const double refl = r0 + (1.0 - r0) * powi5(1.0 - cos_theta);
+    const double xi = rng.range(0.0, 1.0);
+    d3 nd;
+    if (cannot_refract || refl > xi) {
+      nd = normalize(2.0 * dot(camera_dir, n) * n - camera_dir);
+    } else {
+      // refract, src/main.rs:320-327
+      const d3 uv = -1.0 * camera_dir;
+      const double ct = fmin(dot(-1.0 * uv, n), 1.0);
+      const d3 r_out_perp = eta * (uv + ct * n);
+      const d3 r_out_parallel = -sqrt(fabs(1.0 - dot(r_out_perp, r_out_perp))) * n;
+      nd = normalize(r_out_perp + r_out_parallel);
+    }
+    o = hit_pos + eps * nd;  // src/main.rs:966
+    dir = nd;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// camera — src/main.rs:995-1013
+// ------------------------------------------------------------------------------------------
+struct CameraK {
+  double tan_half;  // (fov_y / 2).tan(), computed on the host
+  double aspect;    // width / height
+  double dof;
+  uint32_t width, height;
+  uint32_t jitter;
+};
+
+__device__ __forceinline__ void camera_ray(const CameraK& cam, uint32_t u, uint32_t v, uint64_t key, d3& o, d3& dir) {
+  Rng rng;
+  rng.start(key, 0u);
+  double x_offset = rng.range(-0.3, 0.3);
+  double y_offset = rng.range(-0.3, 0.3);
+  if (!cam.jitter) {
+    x_offset = 0.0;
+    y_offset = 0.0;
+  }
+  const double p_x = (2.0 * (((double)u + 0.5 + x_offset) / (double)cam.width) - 1.0) * cam.tan_half * cam.aspect;
+  const double p_y = (1.0 - 2.0 * (((double)v + 0.5 + y_offset) / (double)cam.height)) * cam.tan_half;
+  const double ox = rng.range(-cam.dof, cam.dof);
+  const double oy = rng.range(-cam.dof, cam.dof);
+  o = mk(ox, oy, 0.0);
+  const d3 d = 2.4 * normalize(mk(p_x, p_y, -1.0));
+  dir = normalize(d - o);
+}
+
+}  // namespace rtk
+
+#endif  // RT_KERNELS_HIP_H

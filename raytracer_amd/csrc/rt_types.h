@@ -1,0 +1,107 @@
+// rt_types.h — records shared by the host scene builder and the gfx950 kernels.
+//
+// Everything the kernels read lives in HBM as arrays of fixed-size, 16-byte-aligned records so
+// that one lane fetches one record with a few dwordx4 loads:
+//
+//   BvhNode   64 B  both child boxes (f32, rounded outward and padded) + both child refs
+//   TriGeom   80 B  a, b-a, c-a in binary64 (what src/main.rs:188-189 computes first) + ids
+//   TriShade 128 B  per-corner vertex normals and texture coordinates (src/main.rs:526-531,
+//                   481-486 with the index lookups already resolved)
+//   Sphere    48 B  centre, radius, object index (src/main.rs:437-442)
+//   rt_material     one per object (include/rt_amd.h)
+//
+// TriGeom and TriShade are stored in leaf order: a leaf names a run of 1..4 consecutive slots.
+#ifndef RT_TYPES_H
+#define RT_TYPES_H
+
+#include <stdint.h>
+
+#include "../../include/rt_amd.h"
+
+#define RT_LEAF_MAX 4                 /* triangles per leaf                                  */
+#define RT_BVH_MAX_DEPTH 62           /* builder guarantee; the traversal stack is sized by it */
+#define RT_REF_SENTINEL INT32_MIN     /* bottom of the traversal stack / empty tree          */
+#define RT_REJECT_CAP 64              /* tries per rejection loop before the fallback        */
+
+// A child ref >= 0 is the index of an interior node. A ref < 0 other than RT_REF_SENTINEL is a
+// leaf: ~ref = first_slot * 4 + (count - 1).
+struct alignas(16) BvhNode {
+  float bx[4];  // child0.min.x child0.max.x child1.min.x child1.max.x
+  float by[4];
+  float bz[4];
+  int32_t child[2];
+  int32_t pad[2];
+};
+
+struct alignas(16) TriGeom {
+  double a[3];
+  double ab[3];  // b - a
+  double ac[3];  // c - a
+  int32_t flat;  // index in the reference's flat triangle order (tie-break, src/main.rs:791)
+  int32_t obj;   // FlatTriangle.obj_idx
+};
+
+struct alignas(16) TriShade {
+  double n[3][3];   // vertex normal per corner
+  double uv[3][2];  // texture coordinate per corner
+  int32_t tri;      // FlatTriangle.triangle_idx
+  int32_t obj;
+};
+
+struct alignas(16) SphereRec {
+  double c[3];
+  double r;
+  int32_t obj;
+  int32_t pad[3];
+};
+
+struct TextureRec {
+  const uint8_t* rgba;  // device pointer, row-major RGBA8, row 0 on top
+  uint32_t w, h;
+};
+
+static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+static_assert(sizeof(TriGeom) == 80, "TriGeom must be 80 bytes");
+static_assert(sizeof(TriShade) == 128, "TriShade must be 128 bytes");
+static_assert(sizeof(SphereRec) == 48, "SphereRec must be 48 bytes");
+
+// Host-side scene: the flat description (owned copies) plus the built tree. The device half
+// is created by rt_scene_upload.
+#ifdef __cplusplus
+#include <string>
+#include <vector>
+
+struct HostTexture {
+  uint32_t w = 0, h = 0;
+  std::vector<uint8_t> rgba;
+};
+
+struct DeviceScene;  // rt_device.hip
+
+struct rt_scene {
+  // flat description, reference order
+  std::vector<int32_t> object_kind;
+  std::vector<rt_material> materials;
+  std::vector<double> tri_vertices, tri_normals, tri_uvs;
+  std::vector<int32_t> tri_obj, tri_idx;
+  std::vector<SphereRec> spheres;
+  std::vector<HostTexture> textures;
+  // acceleration structure
+  std::vector<BvhNode> nodes;
+  std::vector<int32_t> leaf_order;  // slot -> flat index
+  std::vector<TriGeom> tri_geom;    // leaf order
+  std::vector<TriShade> tri_shade;  // leaf order
+  int32_t root_ref = RT_REF_SENTINEL;
+  uint32_t bvh_depth = 0;
+  uint32_t bvh_leaves = 0;
+  DeviceScene* dev = nullptr;
+};
+
+// rt_host.cpp
+void rt_set_error(const char* fmt, ...);
+// rt_device.hip
+void rt_device_scene_free(DeviceScene* d);
+int rt_device_scene_info(const DeviceScene* d, uint32_t* device_plus_one, uint64_t* bytes);
+#endif
+
+#endif  // RT_TYPES_H

@@ -1,0 +1,169 @@
+"""The oracle against hand-derived known answers (tests/golden/kat.json) and against the one
+reference output the repository holds (its committed screenshot). CPU only."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KAT = json.load(open(os.path.join(HERE, "golden", "kat.json")))
+
+
+def test_triangle_known_answers(oracle):
+    for name in ("floor_down", "unit_tri", "unit_tri_back", "unit_tri_dir2"):
+        k = KAT[name]
+        r = oracle.intersects_triangle(k["o"], k["d"], k["a"], k["b"], k["c"])
+        assert r is not None, name
+        assert r[0] == pytest.approx(k["t"], rel=1e-15, abs=1e-15), name
+        assert r[1] == pytest.approx(k["u"], rel=1e-14, abs=1e-15), name
+        assert r[2] == pytest.approx(k["v"], rel=1e-14, abs=1e-15), name
+
+
+def test_triangle_early_outs(oracle):
+    for i, k in enumerate(KAT["misses"]):
+        assert oracle.intersects_triangle(k["o"], k["d"], k["a"], k["b"], k["c"]) is None, i
+    for i, k in enumerate(KAT["edge_hits"]):
+        r = oracle.intersects_triangle(k["o"], k["d"], k["a"], k["b"], k["c"])
+        assert r == (k["t"], k["u"], k["v"]), i
+
+
+def test_triangle_epsilon_window(oracle):
+    # |det| < 1e-8 is rejected, just above is accepted (src/main.rs:205): det = dir.z * 1 here
+    a, b, c = [0, 0, -1], [1, 0, -1], [0, 1, -1]
+    assert oracle.intersects_triangle([0.25, 0.25, 0], [0, 0, -0.9e-8], a, b, c) is None
+    assert oracle.intersects_triangle([0.25, 0.25, 0], [0, 0, -1.1e-8], a, b, c) is not None
+    # dist must exceed 1e-8 (src/main.rs:234)
+    assert oracle.intersects_triangle([0.25, 0.25, -1 + 0.9e-8], [0, 0, -1], a, b, c) is None
+    assert oracle.intersects_triangle([0.25, 0.25, -1 + 1.1e-8], [0, 0, -1], a, b, c) is not None
+
+
+def test_sphere_known_answers(oracle):
+    for i, k in enumerate(KAT["sphere"]):
+        t = oracle.intersects_sphere(k["c"], k["r"], k["o"], k["d"])
+        if k["t"] is None:
+            assert t is None, i
+        else:
+            assert t == pytest.approx(k["t"], rel=1e-15), i
+
+
+def test_sky(oracle):
+    k = KAT["sky_light"]
+    assert np.allclose(oracle.interp_sky(k["d"]), k["rgb"], rtol=1e-14)
+    t = ((2 / math.sqrt(6) + 1) / 2) ** 6
+    assert np.allclose(oracle.interp_sky([0, 1, 0]), [(1 - t) * 0.8 + t * 1.5] * 3, rtol=1e-14)
+    # opposite the light: t = 0 exactly? (d.L + 1)/2 is ~1e-17, so the gradient alone remains
+    d = -np.array(k["d"])
+    want = d[1] * np.array([0.8, 0.8, 0.8]) + (1 - d[1]) * np.array([0.4, 0.6, 0.8])
+    assert np.allclose(oracle.interp_sky(d), want, rtol=1e-12)
+
+
+def test_optics(oracle):
+    for k in KAT["reflectance"]:
+        assert oracle.reflectance(k["cos"], k["ri"]) == pytest.approx(k["r"], rel=1e-14)
+    k = KAT["refract_normal"]
+    assert np.allclose(oracle.refract(k["uv"], k["n"], k["eta"]), k["out"], atol=1e-15)
+    # Snell: 45 degrees into glass, sin(theta_t) = sin(45)/1.5
+    s = math.sqrt(0.5)
+    out = oracle.refract([s, 0, s], [0, 0, 1], 1 / 1.5)  # uv points away from the surface
+    assert np.linalg.norm(out) == pytest.approx(1.0, rel=1e-14)
+    assert abs(out[0]) == pytest.approx(s / 1.5, rel=1e-14)
+    assert out[2] < 0
+
+
+def test_normal_map_flat_texel_keeps_normal(oracle):
+    # texel (128,128,255): normalised first, then 2n-1 (src/main.rs:359, 368) — not exactly +z,
+    # but within the 8-bit quantisation of it
+    n = oracle.normal_map([128, 128, 255], [0, 0, 1])
+    assert np.linalg.norm(n) == pytest.approx(1.0, rel=1e-14)
+    assert n[2] > 0.6
+    # degenerate tangent: world normal parallel to +y takes the z-axis fallback (src/main.rs:362)
+    n = oracle.normal_map([128, 128, 255], [0, 1, 0])
+    assert np.all(np.isfinite(n)) and np.linalg.norm(n) == pytest.approx(1.0, rel=1e-14)
+
+
+def test_rng_uniformity_and_independence(oracle):
+    u = np.array([oracle.rng_u01(0, p, s, 1, i) for p in range(20) for s in range(10) for i in range(10)])
+    assert u.min() >= 0.0 and u.max() < 1.0
+    assert abs(u.mean() - 0.5) < 0.02 and abs(u.var() - 1 / 12) < 0.01
+    assert len(np.unique(u)) == len(u)
+    # different stages / seeds give different streams
+    assert oracle.rng_u01(0, 1, 1, 0, 0) != oracle.rng_u01(0, 1, 1, 1, 0)
+    assert oracle.rng_u01(0, 1, 1, 0, 0) != oracle.rng_u01(1, 1, 1, 0, 0)
+
+
+def test_unit_sphere_sampler(oracle):
+    pts = []
+    for i in range(2000):
+        v, after = oracle.random_unit_sphere_surface(12345 + i, 1, 0)
+        assert after >= 2 and after % 2 == 0
+        pts.append(v)
+    pts = np.array(pts)
+    assert np.allclose(np.linalg.norm(pts, axis=1), 1.0, rtol=1e-12)
+    assert np.all(np.abs(pts.mean(axis=0)) < 0.06)  # uniform on the sphere: mean ~ 0
+
+
+def test_obj_loader_counts(oracle):
+    a = oracle.ASSETS
+    assert oracle.load_obj_counts(os.path.join(a, "triangle_floor.obj")) == (3, 1, 1)
+    assert oracle.load_obj_counts(os.path.join(a, "sphere.obj"))[1] == 320
+    nv, nt, nuv = oracle.load_obj_counts(os.path.join(a, "spot_triangulated.obj"))
+    assert nt == 5856 and nuv > 1
+    assert oracle.load_obj_counts(os.path.join(a, "ogre", "bs_rest.obj"))[1] == 39856
+
+
+def test_scene_inventory(oracle):
+    assert oracle.OracleScene.build("spot").counts() == (5857, 6, 8)
+    assert oracle.OracleScene.build("sphere_floor").counts() == (321, 0, 2)
+    assert oracle.OracleScene.build("ogre").counts() == (39857, 0, 2)
+    assert oracle.OracleScene.build("lens").counts() == (5857, 1, 3)
+
+
+def test_brute_force_equals_reference_like_candidates(oracle):
+    """Nearest hit does not depend on the acceleration structure: the exhaustive f64 test over all
+    triangles and the model of the crate's f32-culled candidate list agree on every camera ray."""
+    for name, w, h in (("spot", 160, 120), ("sphere_floor", 96, 54), ("ogre", 80, 45)):
+        s = oracle.OracleScene.build(name)
+        o, d = oracle.camera_rays(w, h)
+        assert np.array_equal(s.hit(o, d, oracle.HIT_BRUTE), s.hit(o, d, oracle.HIT_REFLIKE)), name
+
+
+def test_primary_hit_fixtures(oracle):
+    import hashlib
+
+    def sha(a):
+        return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+    for name, w, h in (("spot", 160, 120), ("sphere_floor", 192, 108)):
+        g = np.load(os.path.join(HERE, "golden", f"primary_{name}_{w}x{h}.npz"))
+        s = oracle.OracleScene.build(name)
+        o, d = oracle.camera_rays(w, h)
+        hit = s.hit(o, d)
+        for f in ("obj", "tri", "t", "u", "v"):
+            assert sha(hit[f]) == str(g[f"sha_{f}"]), (name, f)
+
+
+def test_screenshot_pin(oracle):
+    """The oracle's converged Spot image against 8x8 block means of the screenshot the reference's
+    authors committed (images/20220206_170941.png). The screenshot used the 20000^2 texture and an
+    unknown sample count, so the comparison is statistical: mean absolute block difference."""
+    from PIL import Image
+
+    import raytracer_amd as rt
+
+    ref = np.asarray(Image.open(os.path.join(HERE, "golden", "ref_screenshot_blocks_200x150.png")), dtype=np.float64) / 255.0
+    s = oracle.OracleScene.build("spot")
+    p = rt.render_params(width=200, height=150, spp=256, seed=3)
+    c = np.zeros((150, 200, 3))
+    s.render(c, p, threads=8, mode=oracle.HIT_REFLIKE)
+    img = np.clip(c, 0.0, 1.0)
+    diff = np.abs(img - ref)
+    # measured: 0.0069 at 256 spp (0.0129 at 48 spp: sampling noise), of which 0.002 is the
+    # screenshot's truncating u8 quantisation (src/main.rs:32-35)
+    assert diff.mean() < 0.009, diff.mean()
+    assert abs((img - ref).mean() - 0.5 / 255) < 0.0015
+    # structure, not just average colour: block-wise correlation per channel
+    for ch in range(3):
+        assert np.corrcoef(img[..., ch].ravel(), ref[..., ch].ravel())[0, 1] > 0.985
+    assert np.percentile(diff, 99) < 0.08

@@ -1,0 +1,272 @@
+"""Parity of the HIP path with the oracle, through the C ABI, on a real MI355X.
+
+Bars: hit records (object id, triangle id, distance, barycentrics) bit-exact; ray counts equal;
+images within 1e-12 relative (the kernels carry throughput as a running product where the
+reference recursion multiplies on the way back, and evaluate the sky's x^6 in double-double
+where the reference calls pow — both affect colour only, in the last bits)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import raytracer_amd as rt
+from raytracer_amd import _ffi, scenes
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+IMG_RTOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def gpu_scenes():
+    if rt.device_count() < 1:
+        pytest.fail("no HIP device visible: the GPU tests cannot run (there is no CPU fallback)")
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            s = scenes.build(name)
+            s.upload(0)
+            cache[name] = s
+        return cache[name]
+
+    return get
+
+
+def rel_err(a, b):
+    return np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("name,w,h", [("spot", 160, 120), ("sphere_floor", 192, 108), ("ogre", 160, 90), ("lens", 80, 60)])
+def test_primary_hits_bit_exact(gpu_scenes, oracle, name, w, h):
+    s = gpu_scenes(name)
+    o = oracle.OracleScene.build(name)
+    obj, tri, t, u, v = s.primary_hits(rt.render_params(width=w, height=h))
+    co, cd = oracle.camera_rays(w, h)
+    want = o.hit(co, cd)
+    assert np.array_equal(obj.ravel(), want["obj"])
+    assert np.array_equal(tri.ravel(), want["tri"])
+    for got, f in ((t, "t"), (u, "u"), (v, "v")):
+        assert got.ravel().tobytes() == want[f].tobytes(), f
+    g = os.path.join(HERE, "golden", f"primary_{name}_{w}x{h}.npz")
+    if os.path.exists(g):
+        g = np.load(g)
+        for got, f in ((obj, "obj"), (tri, "tri"), (t, "t"), (u, "u"), (v, "v")):
+            assert sha(got) == str(g[f"sha_{f}"]), f
+
+
+def test_primary_hits_full_resolution_fixture(gpu_scenes):
+    """Spot at the reference's default 1600x1200 against the committed fixture (hashes + crop)."""
+    g = np.load(os.path.join(HERE, "golden", "primary_spot_1600x1200.npz"))
+    obj, tri, t, u, v = gpu_scenes("spot").primary_hits(rt.render_params(width=1600, height=1200))
+    for got, f in ((obj, "obj"), (tri, "tri"), (t, "t"), (u, "u"), (v, "v")):
+        assert sha(got) == str(g[f"sha_{f}"]), f
+    y0, x0 = g["crop_origin"]
+    crop = g["crop"]
+    assert np.array_equal(obj[y0:y0 + 16, x0:x0 + 16], crop["obj"])
+    assert np.array_equal(t[y0:y0 + 16, x0:x0 + 16], crop["t"])
+
+
+@pytest.mark.parametrize("name", ["spot", "sphere_floor", "ogre"])
+def test_trace_random_and_adversarial_rays(gpu_scenes, oracle, name):
+    from test_host_parity import _adversarial_rays
+
+    s = gpu_scenes(name)
+    o = oracle.OracleScene.build(name)
+    tv = s.export_flat()[0]
+    rng = np.random.default_rng(11)
+    n = 6000 if name != "ogre" else 2500
+    ro = rng.normal(size=(n, 3)) * 2.0 + np.array([0, 0.5, -2.5]); rd = rng.normal(size=(n, 3))
+    ao, ad = _adversarial_rays(rng, tv, n)
+    org = np.concatenate([ro, ao]); d = np.concatenate([rd, ad])
+    got = s.hit(org, d)
+    want = o.hit(org, d)
+    assert got.tobytes() == want.tobytes()
+    st = s.last_stats()
+    assert st.rays == len(org) and st.tri_tests > 0
+
+
+def test_trace_edge_cases(gpu_scenes, oracle):
+    s = gpu_scenes("spot")
+    o = oracle.OracleScene.build("spot")
+    # empty batch
+    assert len(s.hit(np.zeros((0, 3)), np.zeros((0, 3)))) == 0
+    # zero direction, NaN, infinities: no hit, no hang
+    org = np.array([[0, 0, 0], [0, 0, 0], [np.nan, 0, 0], [0, 0, 0], [1e300, 0, 0]], dtype=np.float64)
+    d = np.array([[0, 0, 0], [np.nan, 0, -1], [0, 0, -1], [np.inf, 0, -1], [0, 0, -1]], dtype=np.float64)
+    got = s.hit(org, d)
+    want = o.hit(org, d)
+    assert np.array_equal(got["obj"], want["obj"])
+    # a ray from inside a sphere returns the far root (src/main.rs:254-259)
+    got = s.hit([[-0.3, -0.2, -2.8]], [[0, 0, 1]])
+    want = o.hit([[-0.3, -0.2, -2.8]], [[0, 0, 1]])
+    assert got.tobytes() == want.tobytes() and got["tri"][0] == -1 and got["t"][0] == 0.5
+
+
+def test_sphere_only_and_single_triangle_scenes(oracle):
+    mat = rt.Opaque((0.5, 0.5, 0.5), 0, 1, 0)
+    args = ([_ffi.RT_OBJ_SPHERE], [mat], np.zeros((0, 9)), [], [], [], [], [[0, 0, -3, 1]], [0])
+    s = rt.Scene.from_desc(*args)
+    o = oracle.OracleScene.from_desc_arrays(*args)
+    co, cd = oracle.camera_rays(32, 24)
+    assert s.hit(co, cd).tobytes() == o.hit(co, cd).tobytes()
+    tv = np.array([[[-1, -1, -2], [1, -1, -2], [0, 1, -2]]], dtype=np.float64)
+    tn = np.tile(np.array([0, 0, 1.0]), (1, 3, 1)); tuv = np.zeros((1, 3, 2))
+    args = ([_ffi.RT_OBJ_MESH], [mat], tv, tn, tuv, [0], [0], np.zeros((0, 4)), [])
+    s = rt.Scene.from_desc(*args)
+    o = oracle.OracleScene.from_desc_arrays(*args)
+    got = s.hit(co, cd)
+    assert got.tobytes() == o.hit(co, cd).tobytes() and (got["obj"] >= 0).any()
+    p = rt.render_params(width=32, height=24, spp=3, seed=2)
+    c = np.zeros((24, 32, 3)); oc = np.zeros((24, 32, 3))
+    assert s.render(c, p) == o.render(oc, p)[0]
+    assert rel_err(c, oc) < IMG_RTOL
+
+
+def test_equal_distance_ties_take_lowest_flat_index(oracle):
+    """Two coincident triangles: the reference's strict < keeps the first in flat order."""
+    mat = rt.Opaque((0.5, 0.5, 0.5), 0, 1, 0)
+    one = np.array([[-1, -1, -2], [1, -1, -2], [0, 1, -2]], dtype=np.float64)
+    k = 9
+    tv = np.tile(one, (k, 1, 1)); tn = np.tile(np.array([0, 0, 1.0]), (k, 3, 1)); tuv = np.zeros((k, 3, 2))
+    args = ([_ffi.RT_OBJ_MESH] * 3, [mat] * 3, tv, tn, tuv, [0, 0, 0, 1, 1, 1, 2, 2, 2], [0, 1, 2] * 3, np.zeros((0, 4)), [])
+    s = rt.Scene.from_desc(*args)
+    o = oracle.OracleScene.from_desc_arrays(*args)
+    co, cd = oracle.camera_rays(24, 18)
+    got = s.hit(co, cd)
+    assert got.tobytes() == o.hit(co, cd).tobytes()
+    hit = got[got["obj"] >= 0]
+    assert len(hit) and np.all(hit["obj"] == 0) and np.all(hit["tri"] == 0)
+
+
+@pytest.mark.parametrize("name,w,h,spp", [("spot", 96, 72, 4), ("sphere_floor", 96, 54, 6), ("ogre", 64, 36, 3), ("lens", 64, 48, 3)])
+def test_render_matches_oracle(gpu_scenes, oracle, name, w, h, spp):
+    s = gpu_scenes(name)
+    o = oracle.OracleScene.build(name)
+    p = rt.render_params(width=w, height=h, spp=spp, seed=42)
+    c = np.zeros((h, w, 3)); oc = np.zeros((h, w, 3))
+    rays = s.render(c, p)
+    orays, _ = o.render(oc, p)
+    assert rays == orays
+    assert rel_err(c, oc) < IMG_RTOL
+    assert c.mean() > 0.1
+
+
+def test_render_accumulates_and_is_progressive(gpu_scenes, oracle):
+    """render adds into the canvas (src/main.rs:1035-1037); successive frames use successive
+    samples; frames of spp a and b equal one frame's sample streams a+b."""
+    s = gpu_scenes("spot")
+    o = oracle.OracleScene.build("spot")
+    w, h = 64, 48
+    c = np.full((h, w, 3), 0.25); oc = np.full((h, w, 3), 0.25)
+    for its in range(3):
+        p = rt.render_params(width=w, height=h, spp=2, first_sample=2 * its, seed=9)
+        s.render(c, p)
+        o.render(oc, p)
+    assert rel_err(c, oc) < IMG_RTOL
+    one = np.zeros((h, w, 3))
+    s.render(one, rt.render_params(width=w, height=h, spp=6, seed=9))
+    assert np.allclose((c - 0.25) / 3.0, one, rtol=1e-12, atol=1e-14)
+
+
+def test_render_variants_are_bitwise_identical(gpu_scenes, monkeypatch):
+    """Path regeneration, one-thread-per-path, the counting build and sample chunking all produce
+    the same bits: the result depends only on (seed, pixel, sample)."""
+    s = gpu_scenes("spot")
+    w, h, spp = 72, 40, 5
+    base = np.zeros((h, w, 3))
+    rays = s.render(base, rt.render_params(width=w, height=h, spp=spp, seed=5))
+    for flags in (_ffi.RT_FLAG_NO_REGEN, _ffi.RT_FLAG_COUNT_WORK, _ffi.RT_FLAG_NO_REGEN | _ffi.RT_FLAG_COUNT_WORK, _ffi.RT_FLAG_TIMING):
+        c = np.zeros((h, w, 3))
+        assert s.render(c, rt.render_params(width=w, height=h, spp=spp, seed=5, flags=flags)) == rays
+        assert c.tobytes() == base.tobytes(), flags
+    st_paths = None
+    c = np.zeros((h, w, 3))
+    s.render(c, rt.render_params(width=w, height=h, spp=spp, seed=5, flags=_ffi.RT_FLAG_COUNT_WORK))
+    st = s.last_stats()
+    assert st.rays == rays and st.paths == w * h * spp and st.node_visits > st.rays and st.shaded_hits < st.rays
+    monkeypatch.setenv("RT_SAMPLE_BUFFER_MIB", "1")  # forces several sample chunks
+    c = np.zeros((h, w, 3))
+    s2 = scenes.build("spot")
+    assert s2.render(c, rt.render_params(width=w, height=h, spp=spp, seed=5)) == rays
+    assert c.tobytes() == base.tobytes()
+
+
+def test_tile_split_union_equals_whole(gpu_scenes):
+    s = gpu_scenes("sphere_floor")
+    w, h, spp = 200, 120, 3  # not multiples of the tile size
+    whole = np.zeros((h, w, 3))
+    rays = s.render(whole, rt.render_params(width=w, height=h, spp=spp, seed=1))
+    parts = np.zeros((h, w, 3))
+    total = 0
+    for r in range(3):
+        total += s.render(parts, rt.render_params(width=w, height=h, spp=spp, seed=1, tile_size=32, tile_rank=r, tile_ranks=3))
+    assert total == rays and parts.tobytes() == whole.tobytes()
+
+
+def test_sample_split_sums_to_whole(gpu_scenes):
+    """Samples split over ranks: each renders its share with spp_total as the divisor."""
+    s = gpu_scenes("spot")
+    w, h = 64, 48
+    whole = np.zeros((h, w, 3))
+    s.render(whole, rt.render_params(width=w, height=h, spp=8, seed=3))
+    parts = np.zeros((h, w, 3))
+    for r in range(4):
+        s.render(parts, rt.render_params(width=w, height=h, spp=2, first_sample=2 * r, spp_total=8, seed=3))
+    assert np.allclose(parts, whole, rtol=1e-13, atol=1e-15)
+
+
+def test_depth_cap_and_dof(gpu_scenes, oracle):
+    s = gpu_scenes("spot")
+    o = oracle.OracleScene.build("spot")
+    for kw in (dict(max_depth=0), dict(max_depth=1), dict(max_depth=3), dict(dof_strength=0.05), dict(fov_y_deg=35.0)):
+        p = rt.render_params(width=48, height=36, spp=2, seed=8, **kw)
+        c = np.zeros((36, 48, 3)); oc = np.zeros((36, 48, 3))
+        assert s.render(c, p) == o.render(oc, p)[0], kw
+        assert rel_err(c, oc) < IMG_RTOL, kw
+
+
+def test_parameter_errors(gpu_scenes):
+    s = gpu_scenes("sphere_floor")
+    c = np.zeros((8, 8, 3))
+    for kw in (dict(max_depth=-1), dict(fov_y_deg=0.0), dict(dof_strength=-1.0), dict(tile_size=12, tile_ranks=2)):
+        with pytest.raises(_ffi.RtError) as e:
+            s.render(c, rt.render_params(width=8, height=8, spp=1, **kw))
+        assert e.value.code == _ffi.RT_ERR_INVALID
+    assert s.render(c, rt.render_params(width=8, height=8, spp=0)) == 0 and not c.any()
+
+
+def test_screenshot_pin_gpu(gpu_scenes):
+    """The HIP path's converged Spot image against block means of the reference's screenshot."""
+    from PIL import Image
+
+    ref = np.asarray(Image.open(os.path.join(HERE, "golden", "ref_screenshot_blocks_200x150.png")), dtype=np.float64) / 255.0
+    c = np.zeros((150, 200, 3))
+    gpu_scenes("spot").render(c, rt.render_params(width=200, height=150, spp=1024, seed=3))
+    img = np.clip(c, 0.0, 1.0)
+    diff = np.abs(img - ref)
+    assert diff.mean() < 0.007, diff.mean()
+    assert np.percentile(diff, 99) < 0.08
+
+
+def test_full_size_properties(gpu_scenes):
+    """BASELINE configuration 2 at full size (1920x1080, 64 spp): determinism, sample-stream
+    additivity and ray-count additivity — properties that need no CPU reference."""
+    s = gpu_scenes("sphere_floor")
+    w, h = 1920, 1080
+    a = np.zeros((h, w, 3))
+    rays = s.render(a, rt.render_params(width=w, height=h, spp=64, seed=0))
+    b = np.zeros((h, w, 3))
+    assert s.render(b, rt.render_params(width=w, height=h, spp=64, seed=0)) == rays
+    assert sha(a) == sha(b)
+    halves = np.zeros((h, w, 3))
+    r1 = s.render(halves, rt.render_params(width=w, height=h, spp=32, first_sample=0, spp_total=64, seed=0))
+    r2 = s.render(halves, rt.render_params(width=w, height=h, spp=32, first_sample=32, spp_total=64, seed=0))
+    assert r1 + r2 == rays
+    assert np.allclose(halves, a, rtol=1e-13, atol=1e-15)
+    assert rays > w * h * 64 and np.isfinite(a).all() and a.min() >= 0.0

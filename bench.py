@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""Benchmark of the render hot path on N MI355X GPUs (one process per GPU).
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step is one frame: one call of the library's render entry point over the whole image at the
+workload's samples per pixel, with the scene and the accumulation buffer already in HBM. The
+default workload is BASELINE.json configs[1] (floor + sphere.obj, 1920x1080, 64 spp, depth cap
+200). With N > 1 every rank renders the same frame with its own block of each pixel's sample
+stream (weak scaling: per-GPU work fixed) into an fp32 sum buffer, and one RCCL all-reduce per
+step combines the buffers. Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (scene, width, height, spp, BASELINE.json config it is)
+    "sphere_floor_1080p_64spp": ("sphere_floor", 1920, 1080, 64, "configs[1]"),
+    "ogre_4k_256spp": ("ogre", 3840, 2160, 256, "configs[2]"),
+    "spot_4k_1024spp": ("spot", 3840, 2160, 1024, "configs[3]"),
+    "spot_default_10spp": ("spot", 1600, 1200, 10, "configs[0]"),
+    "spot_grid14_8k_4spp": ("spot_grid:14x14", 7680, 4320, 4, "configs[4] (1 spp-block of it)"),
+}
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec
+FP64_PEAK_TFLOPS = 78.6
+FP32_PEAK_TFLOPS = 157.3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="sphere_floor_1080p_64spp", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-spp", type=int, default=0, help="spp of the CPU baseline sample (0 = auto)")
+    ap.add_argument("--no-regen", action="store_true", help="one thread per path (A/B against path regeneration)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import raytracer_amd as rt
+    from raytracer_amd import _ffi, parallel, scenes
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if rt.device_count() < 1 or not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device; the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    scene_name, W, H, spp, cfg = WORKLOADS[args.workload]
+    scene = scenes.build(scene_name)
+    scene.upload(local_rank)
+    info = scene.info()
+    stream = torch.cuda.current_stream().cuda_stream
+    base_flags = _ffi.RT_FLAG_NO_REGEN if args.no_regen else 0
+
+    def frame_params(step, flags):
+        p = rt.render_params(width=W, height=H, spp=spp, first_sample=step * spp * world, seed=0, flags=flags | base_flags)
+        return parallel.weak_samples(p, rank, world) if world > 1 else p
+
+    canvas = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda") if world == 1 else None
+    sum32 = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") if world > 1 else None
+
+    def run_step(step, flags):
+        p = frame_params(step, flags)
+        if world == 1:
+            scene.render_device(canvas.data_ptr(), p, stream)
+        else:
+            sum32.zero_()
+            scene.render_sum_f32_device(sum32.data_ptr(), p, stream)
+            parallel.reduce_frame_sum(sum32, dist)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # Work counters (node visits, triangle tests per ray) from the counting build of the kernel,
+    # on the first timed frame's parameters, outside the timed region.
+    run_step(args.warmup, _ffi.RT_FLAG_COUNT_WORK)
+    torch.cuda.synchronize()
+    cst = scene.last_stats()
+    per_ray = {
+        "nodes": cst.node_visits / max(1, cst.rays),
+        "tris": cst.tri_tests / max(1, cst.rays),
+        "spheres": cst.sphere_tests / max(1, cst.rays),
+        "shaded": cst.shaded_hits / max(1, cst.rays),
+        "rays_per_path": cst.rays / max(1, cst.paths),
+    }
+    for w_ in range(args.warmup):
+        run_step(w_, 0)
+    if canvas is not None:
+        canvas.zero_()
+
+    rays_total = 0
+    ms_paths = []
+    ms_resolve = []
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        run_step(args.warmup + k, _ffi.RT_FLAG_TIMING)
+        rays_total += scene.last_stats().rays  # waits for the frame, as the reference's display loop does
+        tm = scene.last_timing()
+        ms_paths.append(tm.ms_paths / max(1, tm.path_launches))
+        ms_resolve.append(tm.ms_resolve / max(1, tm.resolve_launches))
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed, float(rays_total)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+        rays_all = float(t[1])
+    else:
+        rays_all = float(rays_total)
+
+    if rank == 0:
+        value = rays_all / elapsed / 1e6
+        # roofline of the dominant kernel (k_paths): algorithmic bytes per ray =
+        # 64 B per interior node visited + 192 B per triangle tested (72 B vertices + 72 B vertex
+        # normals + 48 B texture coordinates) + 48 B ray in + 40 B hit out.
+        bytes_per_ray = 64.0 * per_ray["nodes"] + 192.0 * per_ray["tris"] + 88.0
+        flops_per_ray = 24.0 * per_ray["nodes"] + 52.0 * per_ray["tris"] + 30.0 * per_ray["spheres"]
+        launch_ms = float(np.mean(ms_paths))
+        rays_per_launch = rays_total / max(1, args.steps) / max(1, len(ms_paths) and 1)
+        # a frame may run as several launches (sample chunks); ms_paths is per launch
+        tm = scene.last_timing()
+        rays_per_launch /= max(1, tm.path_launches)
+        achieved = bytes_per_ray * rays_per_launch / (launch_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(args.workload, {}).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s (primary+secondary)",
+            "value": round(value, 2),
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "reference scene files (assets/), counter-based sampling seed 0",
+            "config": {
+                "workload": f"{args.workload} = BASELINE.json {cfg}: scene {scene_name}, {W}x{H}, {spp} spp per GPU per frame, depth cap 200",
+                "triangles": int(info.n_triangles),
+                "spheres": int(info.n_spheres),
+                "bvh_nodes": int(info.bvh_nodes),
+                "sharding": "none" if world == 1 else f"samples: {world} x {spp} spp, one RCCL all-reduce(sum, fp32, {W * H * 3 * 4 / 1e6:.1f} MB) per frame",
+                "path_regeneration": not args.no_regen,
+            },
+            "sec_per_frame": round(elapsed / args.steps, 5),
+            "mrays_per_gpu": round(value / world, 2),
+            "rays_per_frame_per_gpu": int(rays_total / max(1, args.steps)),
+            "per_ray": {k: round(v, 3) for k, v in per_ray.items()},
+            "roofline": {
+                "kernel": "k_paths",
+                "bound": "hbm",
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": traffic,
+                "launch_ms": round(launch_ms, 4),
+                "bytes_per_ray": round(bytes_per_ray, 1),
+                "rays_per_launch": int(rays_per_launch),
+                "resolve_ms": round(float(np.mean(ms_resolve)), 4),
+                "valu": {
+                    "achieved_tflops": round(flops_per_ray * rays_per_launch / (launch_ms * 1e-3) / 1e12, 4),
+                    "flops_per_ray": round(flops_per_ray, 1),
+                    "peak_fp64_tflops": FP64_PEAK_TFLOPS,
+                    "peak_fp32_tflops": FP32_PEAK_TFLOPS,
+                    "note": "traversal slab tests are f32, triangle/sphere tests f64; working set fits L2, so the kernel is VALU/latency bound, not HBM bound",
+                },
+            },
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene_name, W, H, spp, args.cpu_sample_spp)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(scene_name, W, H, spp, sample_spp):
+    """The CPU restatement of the reference's render -> raytrace -> Scene::hit path (oracle/, with
+    the reference's exhaustive-candidate hit semantics), threads over pixels standing in for
+    rayon, timed on this box's host cores on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+
+    import oracle_ffi as orc
+    import raytracer_amd as rt
+
+    threads = min(16, os.cpu_count() or 1)
+    o = orc.OracleScene.build(scene_name)
+    # calibrate on a 1/16-size frame, then size the sample for about 10-20 s
+    p = rt.render_params(width=W // 4, height=H // 4, spp=1, seed=0)
+    c = np.zeros((H // 4, W // 4, 3))
+    t0 = time.perf_counter()
+    rays, _ = o.render(c, p, threads=threads, mode=orc.HIT_REFLIKE)
+    rate = rays / (time.perf_counter() - t0)
+    if sample_spp <= 0:
+        rays_per_spp = rays * 16.0
+        sample_spp = int(max(1, min(spp, 15.0 * rate / rays_per_spp)))
+    p = rt.render_params(width=W, height=H, spp=sample_spp, seed=0)
+    c = np.zeros((H, W, 3))
+    t0 = time.perf_counter()
+    rays, cands = o.render(c, p, threads=threads, mode=orc.HIT_REFLIKE)
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(rays / dt / 1e6, 3),
+        "unit": "Mrays/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{W}x{H}, {sample_spp} of {spp} spp, same scene and seed ({rays} rays in {dt:.1f} s; {cands / max(1, rays):.1f} triangle candidates per ray)",
+    }
+
+
+if __name__ == "__main__":
+    main()

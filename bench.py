@@ -30,6 +30,11 @@ WORKLOADS = {
     "spot_grid14_8k_4spp": ("spot_grid:14x14", 7680, 4320, 4, "configs[4] (1 spp-block of it)"),
 }
 
+FORM_NAMES = {
+    "wave": "wavefront: one launch per bounce over a compacted ray queue",
+    "mega": "single persistent kernel with path regeneration",
+    "noregen": "single kernel, one thread per path",
+}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec
 FP64_PEAK_TFLOPS = 78.6
 FP32_PEAK_TFLOPS = 157.3
@@ -43,7 +48,7 @@ def main():
     ap.add_argument("--workload", default="sphere_floor_1080p_64spp", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-spp", type=int, default=0, help="spp of the CPU baseline sample (0 = auto)")
-    ap.add_argument("--no-regen", action="store_true", help="one thread per path (A/B against path regeneration)")
+    ap.add_argument("--form", default="wave", choices=["wave", "mega", "noregen"], help="scheduling form (A/B); default wavefront")
     args = ap.parse_args()
 
     import numpy as np
@@ -70,7 +75,7 @@ def main():
     scene.upload(local_rank)
     info = scene.info()
     stream = torch.cuda.current_stream().cuda_stream
-    base_flags = _ffi.RT_FLAG_NO_REGEN if args.no_regen else 0
+    base_flags = {"wave": 0, "mega": _ffi.RT_FLAG_MEGAKERNEL, "noregen": _ffi.RT_FLAG_NO_REGEN}[args.form]
 
     def frame_params(step, flags):
         p = rt.render_params(width=W, height=H, spp=spp, first_sample=step * spp * world, seed=0, flags=flags | base_flags)
@@ -93,8 +98,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Work counters (node visits, triangle tests per ray) from the counting build of the kernel,
-    # on the first timed frame's parameters, outside the timed region.
+    # Work counters (node visits, triangle tests per ray, per kernel) from the counting build of
+    # the kernels, on the first timed frame's parameters, outside the timed region.
     run_step(args.warmup, _ffi.RT_FLAG_COUNT_WORK)
     torch.cuda.synchronize()
     cst = scene.last_stats()
@@ -105,22 +110,25 @@ def main():
         "shaded": cst.shaded_hits / max(1, cst.rays),
         "rays_per_path": cst.rays / max(1, cst.paths),
     }
+    counted = {}  # kernel kind -> [rays, node visits, triangle tests]
+    for l in scene.last_launches():
+        c = counted.setdefault(l.kind, [0, 0, 0])
+        c[0] += l.rays; c[1] += l.node_visits; c[2] += l.tri_tests
     for w_ in range(args.warmup):
         run_step(w_, 0)
     if canvas is not None:
         canvas.zero_()
 
     rays_total = 0
-    ms_paths = []
-    ms_resolve = []
+    timed = {}  # kernel kind -> [ms, launches, rays]
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
         run_step(args.warmup + k, _ffi.RT_FLAG_TIMING)
         rays_total += scene.last_stats().rays  # waits for the frame, as the reference's display loop does
-        tm = scene.last_timing()
-        ms_paths.append(tm.ms_paths / max(1, tm.path_launches))
-        ms_resolve.append(tm.ms_resolve / max(1, tm.resolve_launches))
+        for l in scene.last_launches():
+            c = timed.setdefault(l.kind, [0.0, 0, 0])
+            c[0] += l.ms; c[1] += 1; c[2] += l.rays
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -136,17 +144,30 @@ def main():
 
     if rank == 0:
         value = rays_all / elapsed / 1e6
-        # roofline of the dominant kernel (k_paths): algorithmic bytes per ray =
-        # 64 B per interior node visited + 192 B per triangle tested (72 B vertices + 72 B vertex
-        # normals + 48 B texture coordinates) + 48 B ray in + 40 B hit out.
-        bytes_per_ray = 64.0 * per_ray["nodes"] + 192.0 * per_ray["tris"] + 88.0
-        flops_per_ray = 24.0 * per_ray["nodes"] + 52.0 * per_ray["tris"] + 30.0 * per_ray["spheres"]
-        launch_ms = float(np.mean(ms_paths))
-        rays_per_launch = rays_total / max(1, args.steps) / max(1, len(ms_paths) and 1)
-        # a frame may run as several launches (sample chunks); ms_paths is per launch
-        tm = scene.last_timing()
-        rays_per_launch /= max(1, tm.path_launches)
+        # Roofline of the dominant kernel (largest total time in the timed region). Algorithmic
+        # bytes per ray = 64 B per interior node visited + 192 B per triangle tested (72 B
+        # vertices + 72 B vertex normals + 48 B texture coordinates) + 48 B ray in + 40 B hit out,
+        # with that kernel's own per-ray means from the counting build.
+        names = {0: "k_wave<false,0> (camera + trace)", 1: "k_wave<false,1> (shade + trace, ray queue)",
+                 2: "k_wave<false,2> (tail loop)", 3: "k_paths (single-kernel form)", 4: "k_resolve"}
+        dom = max((k for k in timed if k != 4), key=lambda k: timed[k][0])
+        d_ms, d_launches, d_rays = timed[dom]
+        c_rays, c_nodes, c_tris = counted.get(dom, [cst.rays, cst.node_visits, cst.tri_tests])
+        if c_rays == 0:  # the single-kernel form logs no per-launch ray count when not counting
+            c_rays, c_nodes, c_tris = cst.rays, cst.node_visits, cst.tri_tests
+        if d_rays == 0:
+            d_rays = rays_total
+        bytes_per_ray = 64.0 * c_nodes / c_rays + 192.0 * c_tris / c_rays + 88.0
+        flops_per_ray = 24.0 * c_nodes / c_rays + 52.0 * c_tris / c_rays + 30.0 * per_ray["spheres"]
+        launch_ms = d_ms / d_launches
+        rays_per_launch = d_rays / d_launches
         achieved = bytes_per_ray * rays_per_launch / (launch_ms * 1e-3) / 1e9
+        kernels = [
+            {"kernel": names[k], "launches_per_frame": round(v[1] / args.steps, 2), "ms_per_frame": round(v[0] / args.steps, 4),
+             "mrays_per_frame": round(v[2] / args.steps / 1e6, 3)}
+            for k, v in sorted(timed.items())
+        ]
+        ms_resolve = [timed.get(4, [0.0, 1, 0])[0] / max(1, timed.get(4, [0.0, 1, 0])[1])]
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tfile):
@@ -173,14 +194,15 @@ def main():
                 "spheres": int(info.n_spheres),
                 "bvh_nodes": int(info.bvh_nodes),
                 "sharding": "none" if world == 1 else f"samples: {world} x {spp} spp, one RCCL all-reduce(sum, fp32, {W * H * 3 * 4 / 1e6:.1f} MB) per frame",
-                "path_regeneration": not args.no_regen,
+                "form": FORM_NAMES[args.form],
             },
             "sec_per_frame": round(elapsed / args.steps, 5),
             "mrays_per_gpu": round(value / world, 2),
             "rays_per_frame_per_gpu": int(rays_total / max(1, args.steps)),
             "per_ray": {k: round(v, 3) for k, v in per_ray.items()},
+            "kernels": kernels,
             "roofline": {
-                "kernel": "k_paths",
+                "kernel": names[dom],
                 "bound": "hbm",
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS,
@@ -190,6 +212,7 @@ def main():
                 "launch_ms": round(launch_ms, 4),
                 "bytes_per_ray": round(bytes_per_ray, 1),
                 "rays_per_launch": int(rays_per_launch),
+                "launches_per_frame": round(d_launches / args.steps, 2),
                 "resolve_ms": round(float(np.mean(ms_resolve)), 4),
                 "valu": {
                     "achieved_tflops": round(flops_per_ray * rays_per_launch / (launch_ms * 1e-3) / 1e12, 4),

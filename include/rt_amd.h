@@ -48,7 +48,10 @@ extern "C" {
 #define RT_FLAG_NO_JITTER 1u  /* pixel-centre rays: x_offset = y_offset = 0 (parity checks) */
 #define RT_FLAG_TIMING 2u     /* bracket the path kernel with HIP events                    */
 #define RT_FLAG_COUNT_WORK 4u /* run the counting variant: node visits, triangle tests      */
-#define RT_FLAG_NO_REGEN 8u   /* one thread per path, no path regeneration (A/B baseline)   */
+#define RT_FLAG_NO_REGEN 8u   /* single kernel, one thread per path, no regeneration (A/B)  */
+#define RT_FLAG_MEGAKERNEL 16u /* single persistent kernel with path regeneration (A/B); the  */
+                              /* default is the wavefront form: one launch per bounce over a */
+                              /* compacted ray queue                                         */
 
 /* One per object, indexed by object index. Material::Opaque / Material::Dielectric,
  * src/main.rs:414-425; ColorKind src/main.rs:386-390; NormalKind src/main.rs:335-339. */
@@ -148,11 +151,23 @@ typedef struct rt_stats {
 /* Durations of the last call made with RT_FLAG_TIMING, measured with HIP events on the
  * stream the kernels ran on. */
 typedef struct rt_timing {
-  float ms_paths;    /* sum over launches of the path (trace + shade) kernel */
+  float ms_paths;    /* sum over launches of the path (trace + shade) kernels */
   float ms_resolve;  /* sum over launches of the sample-resolve kernel       */
   uint32_t path_launches;
   uint32_t resolve_launches;
 } rt_timing;
+
+/* One kernel launch of the last render call, in launch order. */
+typedef struct rt_launch_info {
+  uint32_t kind;        /* 0 first bounce (camera + trace), 1 bounce (shade + trace) over the ray
+                           queue, 2 tail (loops to the end), 3 single-kernel form, 4 resolve     */
+  uint32_t items;       /* paths / queue entries / pixels the launch started with               */
+  float ms;             /* duration (RT_FLAG_TIMING), else 0                                    */
+  uint32_t reserved;
+  uint64_t rays;        /* nearest-hit queries the launch made                                   */
+  uint64_t node_visits; /* RT_FLAG_COUNT_WORK                                                   */
+  uint64_t tri_tests;   /* RT_FLAG_COUNT_WORK                                                   */
+} rt_launch_info;
 
 typedef struct rt_mesh rt_mesh;       /* PolygonMesh, src/main.rs:566-574 */
 typedef struct rt_objects rt_objects; /* Vec<Object> being assembled      */
@@ -226,6 +241,8 @@ int rt_render_sum_f32_device(rt_scene* scene, const rt_render_params* p, float* 
 /* Waits for the scene's queued work, then reports. */
 int rt_scene_last_stats(rt_scene* scene, rt_stats* out);
 int rt_scene_last_timing(rt_scene* scene, rt_timing* out);
+/* Per-launch log of the last render call: copies up to `capacity` entries, *n_out = total. */
+int rt_scene_last_launches(rt_scene* scene, rt_launch_info* out, uint32_t capacity, uint32_t* n_out);
 
 /* impl Into<Rgba<u8>> for RGBA, src/main.rs:29-37, applied to canvas / its as the display loop
  * does at src/main.rs:1106-1112. Host buffers; out is [height][width][4]. */

@@ -25,6 +25,7 @@ RT_FLAG_NO_JITTER = 1
 RT_FLAG_TIMING = 2
 RT_FLAG_COUNT_WORK = 4
 RT_FLAG_NO_REGEN = 8
+RT_FLAG_MEGAKERNEL = 16
 
 
 class rt_material(C.Structure):
@@ -121,6 +122,18 @@ class rt_timing(C.Structure):
     ]
 
 
+class rt_launch_info(C.Structure):
+    _fields_ = [
+        ("kind", C.c_uint32),
+        ("items", C.c_uint32),
+        ("ms", C.c_float),
+        ("reserved", C.c_uint32),
+        ("rays", C.c_uint64),
+        ("node_visits", C.c_uint64),
+        ("tri_tests", C.c_uint64),
+    ]
+
+
 # Every symbol include/rt_amd.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 SIGNATURES = {
@@ -152,6 +165,7 @@ SIGNATURES = {
     "rt_render_sum_f32_device": (C.c_int, [_P, C.POINTER(rt_render_params), _P, _P]),
     "rt_scene_last_stats": (C.c_int, [_P, C.POINTER(rt_stats)]),
     "rt_scene_last_timing": (C.c_int, [_P, C.POINTER(rt_timing)]),
+    "rt_scene_last_launches": (C.c_int, [_P, C.POINTER(rt_launch_info), C.c_uint32, C.POINTER(C.c_uint32)]),
     "rt_quantize_rgba8": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32, _P]),
     "rt_last_error": (C.c_char_p, []),
 }

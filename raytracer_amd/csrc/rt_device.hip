@@ -4,15 +4,21 @@
 // Kernels
 //   k_trace        batch Scene::hit (src/main.rs:776-814), one ray per lane
 //   k_primary      the pixel-centre camera ray of every pixel + Scene::hit (parity buffer)
-//   k_paths        render's per-sample body (src/main.rs:995-1019) and raytrace (817-975) as an
-//                  iterative loop; lanes that finish a path pull the next (pixel, sample) from a
-//                  work counter, so a wave stays full however unequal the path lengths are
+//   k_wave<STAGE>  render's per-sample body (src/main.rs:995-1019) and raytrace (817-975) in
+//                  wavefront form: one launch per bounce over a compacted queue of live paths
+//   k_paths        the same loop as ONE kernel (per-lane bounce loop, optionally with lanes that
+//                  finish a path pulling the next one from a work counter) — kept for A/B
 //   k_resolve      the per-pixel sums of src/main.rs:1020-1037 in sample order
 //
-// HBM layout: see rt_types.h. The per-sample radiance buffer is [3][n_paths] binary64, where
+// HBM layout: see rt_types.h. The per-sample radiance buffer is [n_paths][3] binary64, where
 // a path index is ((tile * spp + sample) * 64 + pixel-in-tile) over 8x8-pixel tiles, so the 64
-// lanes of a wave start on one tile and one sample (coherent primary rays, coalesced stores)
-// and k_resolve reads 64 consecutive values per sample.
+// lanes of a wave start on one tile and one sample (coherent primary rays), a path's radiance
+// is one 24-byte store, and k_resolve reads 64 consecutive records per sample.
+//
+// Atomics: one word takes ~88 atomic adds per microsecond on this chip, and a 1080p x 64 spp
+// frame has two million waves, so nothing here lets every wave add to the same word. Work
+// counters and queue tails are sharded over RT_SHARDS 128-byte lines; a wave picks its line
+// from its block index, the host sums the lines.
 
 #include <hip/hip_runtime.h>
 
@@ -32,7 +38,12 @@ using namespace rtk;
 // ------------------------------------------------------------------------------------------
 // device scene
 // ------------------------------------------------------------------------------------------
-enum { CNT_RAYS = 0, CNT_NODES, CNT_TRIS, CNT_SPHERES, CNT_SHADED, CNT_PATHS, CNT_QUEUE, CNT_N = 8 };
+#define RT_SHARDS 1024     /* counter lines; also the most queue segments a launch uses */
+#define RT_LINE_WORDS 16   /* 64-bit words per line (128 B)                             */
+#define RT_WORK_BATCH 1024 /* path indices a wave takes from the work counter at a time */
+// words of a line
+enum { CNT_RAYS = 0, CNT_NODES, CNT_TRIS, CNT_SPHERES, CNT_SHADED, CNT_PATHS, CNT_Q0, CNT_Q1, CNT_WORK, CNT_N };
+#define RT_COUNTER_BYTES ((size_t)RT_SHARDS * RT_LINE_WORDS * sizeof(unsigned long long))
 
 struct DeviceScene {
   int device = -1;
@@ -45,11 +56,17 @@ struct DeviceScene {
   size_t samples_bytes = 0;
   double* totals = nullptr;
   size_t totals_bytes = 0;
-  unsigned long long* counters = nullptr;  // CNT_N words
+  void* queue[2] = {nullptr, nullptr};  // QueueRec segments, wavefront form
+  size_t queue_bytes[2] = {0, 0};
+  double* queue_rad[2] = {nullptr, nullptr};  // emitted radiance carried per queue entry
+  size_t queue_rad_bytes[2] = {0, 0};
+  unsigned long long* counters = nullptr;       // RT_SHARDS lines
+  unsigned long long* host_counters = nullptr;  // pinned mirror
   // staging for the host-buffer entry points
   void* stage = nullptr;
   size_t stage_bytes = 0;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  std::vector<hipEvent_t> ev_pool;
+  std::vector<rt_launch_info> launches;
   rt_timing timing{};
   bool have_timing = false;
   hipStream_t last_stream = nullptr;
@@ -73,8 +90,12 @@ void rt_device_scene_free(DeviceScene* d) {
   if (d->totals) (void)hipFree(d->totals);
   if (d->counters) (void)hipFree(d->counters);
   if (d->stage) (void)hipFree(d->stage);
-  for (hipEvent_t e : d->ev)
-    if (e) (void)hipEventDestroy(e);
+  for (int q = 0; q < 2; ++q) {
+    if (d->queue[q]) (void)hipFree(d->queue[q]);
+    if (d->queue_rad[q]) (void)hipFree(d->queue_rad[q]);
+  }
+  if (d->host_counters) (void)hipHostFree(d->host_counters);
+  for (hipEvent_t e : d->ev_pool) (void)hipEventDestroy(e);
   delete d;
 }
 
@@ -145,17 +166,19 @@ extern "C" int rt_scene_upload(rt_scene* s, int device) {
   if ((rc = upload_array(d, trec.data(), trec.size(), &d->k.tex)) != RT_OK) return fail(rc);
   d->k.root_ref = s->root_ref;
   d->k.n_spheres = (uint32_t)s->spheres.size();
+  d->k.has_emission = 0;
+  for (const rt_material& m : s->materials)
+    if (m.emission[0] != 0.0 || m.emission[1] != 0.0 || m.emission[2] != 0.0) d->k.has_emission = 1;
   d->stack_entries = s->bvh_depth + 2;
-  if (hipMalloc((void**)&d->counters, CNT_N * sizeof(unsigned long long)) != hipSuccess) {
+  if (hipMalloc((void**)&d->counters, RT_COUNTER_BYTES) != hipSuccess) {
     rt_set_error("rt_scene_upload: hipMalloc of the counters failed");
     return fail(RT_ERR_HIP);
   }
-  (void)hipMemset(d->counters, 0, CNT_N * sizeof(unsigned long long));
-  for (int i = 0; i < 4; ++i)
-    if (hipEventCreate(&d->ev[i]) != hipSuccess) {
-      rt_set_error("rt_scene_upload: hipEventCreate failed");
-      return fail(RT_ERR_HIP);
-    }
+  (void)hipMemset(d->counters, 0, RT_COUNTER_BYTES);
+  if (hipHostMalloc((void**)&d->host_counters, RT_COUNTER_BYTES, hipHostMallocDefault) != hipSuccess) {
+    rt_set_error("rt_scene_upload: hipHostMalloc of the counter mirror failed");
+    return fail(RT_ERR_HIP);
+  }
   s->dev = d;
   return RT_OK;
 }
@@ -186,10 +209,32 @@ static int ensure_bytes(void** p, size_t* have, size_t want) {
   return RT_OK;
 }
 
+// Copies the counter lines to the host (waits for `stream`) and sums them per word; the queue
+// tails (CNT_Q0/CNT_Q1) are also returned per line.
+struct CounterSums {
+  unsigned long long w[CNT_N];
+};
+static int read_counters(DeviceScene* d, hipStream_t stream, CounterSums* sums) {
+  HIP_TRY(hipMemcpyAsync(d->host_counters, d->counters, RT_COUNTER_BYTES, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  std::memset(sums, 0, sizeof *sums);
+  for (int s = 0; s < RT_SHARDS; ++s)
+    for (int w = 0; w < CNT_N; ++w) sums->w[w] += d->host_counters[(size_t)s * RT_LINE_WORDS + w];
+  return RT_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------
 extern __shared__ int32_t g_stack[];  // [stack_entries][blockDim.x]
+
+__device__ __forceinline__ uint32_t linear_block() { return blockIdx.y * gridDim.x + blockIdx.x; }
+
+// The counter line a wave adds to.
+__device__ __forceinline__ unsigned long long* my_line(unsigned long long* counters) {
+  const uint32_t wave = linear_block() * (RT_BLOCK / 64) + (threadIdx.x >> 6);
+  return counters + (size_t)(wave % RT_SHARDS) * RT_LINE_WORDS;
+}
 
 __device__ __forceinline__ void store_hit(const SceneK& sc, const HitK& h, rt_hit* out) {
   rt_hit r;
@@ -216,24 +261,25 @@ __device__ __forceinline__ void store_hit(const SceneK& sc, const HitK& h, rt_hi
   *out = r;
 }
 
-__device__ __forceinline__ void flush_counts(const WorkCount& wc, unsigned long long* counters, bool count_all) {
-  // one atomic per wave and counter
-  unsigned long long v = wc.rays;
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-  if ((threadIdx.x & 63) == 0 && v) atomicAdd(&counters[CNT_RAYS], v);
+  return v;
+}
+
+__device__ __forceinline__ void flush_counts(const WorkCount& wc, unsigned long long* counters, bool count_all, uint32_t n_done) {
+  // one atomic per wave and counter, on the wave's own line
+  unsigned long long* line = my_line(counters);
+  const unsigned long long r = wave_sum(wc.rays);
+  if ((threadIdx.x & 63) == 0 && r) atomicAdd(&line[CNT_RAYS], r);
   if (count_all) {
-    unsigned long long a = wc.nodes, b = wc.tris, c = wc.spheres, e = wc.shaded;
-    for (int off = 32; off > 0; off >>= 1) {
-      a += __shfl_down(a, off);
-      b += __shfl_down(b, off);
-      c += __shfl_down(c, off);
-      e += __shfl_down(e, off);
-    }
+    const unsigned long long a = wave_sum(wc.nodes), b = wave_sum(wc.tris), c = wave_sum(wc.spheres), e = wave_sum(wc.shaded),
+                             f = wave_sum(n_done);
     if ((threadIdx.x & 63) == 0) {
-      atomicAdd(&counters[CNT_NODES], a);
-      atomicAdd(&counters[CNT_TRIS], b);
-      atomicAdd(&counters[CNT_SPHERES], c);
-      atomicAdd(&counters[CNT_SHADED], e);
+      if (a) atomicAdd(&line[CNT_NODES], a);
+      if (b) atomicAdd(&line[CNT_TRIS], b);
+      if (c) atomicAdd(&line[CNT_SPHERES], c);
+      if (e) atomicAdd(&line[CNT_SHADED], e);
+      if (f) atomicAdd(&line[CNT_PATHS], f);
     }
   }
 }
@@ -251,7 +297,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(SceneK sc, const double* __r
     wc.rays = 1;
     store_hit(sc, h, out + i);
   }
-  flush_counts(wc, counters, COUNT);
+  flush_counts(wc, counters, COUNT, 0);
 }
 
 __global__ __launch_bounds__(RT_BLOCK) void k_primary(SceneK sc, CameraK cam, int32_t* __restrict__ obj, int32_t* __restrict__ tri,
@@ -275,7 +321,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_primary(SceneK sc, CameraK cam, in
     u[i] = r.u;
     v[i] = r.v;
   }
-  flush_counts(wc, counters, false);
+  flush_counts(wc, counters, false, 0);
 }
 
 // Which pixels a call renders and how path indices map onto them.
@@ -309,12 +355,48 @@ struct PathParams {
   CameraK cam;
   TileMap tm;
   uint64_t seed;
-  uint64_t n_paths;       // n_tiles * spp * 64
+  uint32_t n_paths;       // n_tiles * spp * 64, < 2^32 per launch
   uint32_t spp;           // samples in this launch
   uint32_t first_sample;  // stream index of this launch's sample 0
   int32_t max_depth;
 };
 
+// Path index -> pixel and sample; starts the path (camera ray, src/main.rs:995-1013).
+// Returns false for the padding lanes of tiles that overhang the image.
+__device__ __forceinline__ bool start_path(const PathParams& pp, uint32_t path, uint64_t& key, d3& o, d3& dir) {
+  const uint32_t g = path >> 6;  // tile * spp + sample
+  const uint32_t tile = g / pp.spp;
+  const uint32_t s = g - tile * pp.spp;
+  uint32_t x, y;
+  if (!tile_pixel(pp.tm, tile, path & 63u, &x, &y)) return false;
+  key = path_key(pp.seed, (uint64_t)y * pp.tm.width + x, (uint64_t)pp.first_sample + s);
+  camera_ray(pp.cam, x, y, key, o, dir);
+  return true;
+}
+
+__device__ __forceinline__ void store_sample(double* __restrict__ samples, uint32_t n_paths, uint32_t path, const d3 rad) {
+  (void)n_paths;
+  double* p = samples + (size_t)path * 3;
+  p[0] = rad.x;
+  p[1] = rad.y;
+  p[2] = rad.z;
+}
+
+__device__ __forceinline__ ShadeIn shade_input(const HitK& h, const d3 o, const d3 dir) {
+  ShadeIn si;
+  si.hit_pos = o + h.t * dir;  // src/main.rs:831
+  si.u = h.u;
+  si.v = h.v;
+  si.slot = h.slot;
+  si.sphere = h.sphere;
+  return si;
+}
+
+// ------------------------------------------------------------------------------------------
+// Single-kernel form. REGEN: a lane whose path has ended takes the next path index from a work
+// counter (in wave-local batches of RT_WORK_BATCH, so the counter sees one atomic per 1024
+// paths); otherwise one thread per path.
+// ------------------------------------------------------------------------------------------
 template <bool COUNT, bool REGEN>
 __global__ __launch_bounds__(RT_BLOCK) void k_paths(SceneK sc, PathParams pp, double* __restrict__ samples,
                                                     unsigned long long* counters) {
@@ -325,63 +407,53 @@ __global__ __launch_bounds__(RT_BLOCK) void k_paths(SceneK sc, PathParams pp, do
   uint32_t n_done = 0;
 
   bool alive = false;
-  bool exhausted = false;  // wave-uniform: the work counter has run out
-  uint64_t path = 0, key = 0;
+  bool exhausted = false;              // wave-uniform: the work counter has run out
+  uint32_t local_next = 0, local_end = 0;  // wave-uniform: the wave's batch of path indices
+  uint32_t path = 0;
+  uint64_t key = 0;
   int depth = 0;
   d3 o = mk(0, 0, 0), dir = mk(0, 0, 0), thr = mk(1, 1, 1), rad = mk(0, 0, 0);
 
   if (!REGEN) {
-    // one path per thread, in path-index order
-    path = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t p64 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     exhausted = true;
-    if (path < pp.n_paths) {
-      const uint64_t per_tile = (uint64_t)pp.spp * 64u;
-      const uint32_t tile = (uint32_t)(path / per_tile);
-      const uint32_t rem = (uint32_t)(path % per_tile);
-      uint32_t x, y;
-      if (tile_pixel(pp.tm, tile, rem & 63u, &x, &y)) {
-        key = path_key(pp.seed, (uint64_t)y * pp.tm.width + x, (uint64_t)pp.first_sample + (rem >> 6));
-        camera_ray(pp.cam, x, y, key, o, dir);
-        alive = true;
-      } else {
-        samples[path] = 0.0;
-        samples[pp.n_paths + path] = 0.0;
-        samples[2 * pp.n_paths + path] = 0.0;
-      }
+    if (p64 < pp.n_paths) {
+      path = (uint32_t)p64;
+      alive = start_path(pp, path, key, o, dir);
+      if (!alive) store_sample(samples, pp.n_paths, path, mk(0.0, 0.0, 0.0));
     }
   }
 
   for (;;) {
     if (REGEN && !exhausted) {
-      const unsigned long long need = __ballot(!alive);
-      if (need) {
-        const int n = __popcll(need);
-        const int leader = __ffsll((long long)need) - 1;
-        unsigned long long base = 0;
-        if (lane == leader) base = atomicAdd(&counters[CNT_QUEUE], (unsigned long long)n);
-        base = __shfl(base, leader);
-        if (base + (unsigned long long)n >= pp.n_paths) exhausted = true;
-        if (!alive) {
-          path = base + (unsigned long long)__popcll(need & ((1ull << lane) - 1ull));
-          if (path < pp.n_paths) {
-            const uint64_t per_tile = (uint64_t)pp.spp * 64u;
-            const uint32_t tile = (uint32_t)(path / per_tile);
-            const uint32_t rem = (uint32_t)(path % per_tile);
-            uint32_t x, y;
-            if (tile_pixel(pp.tm, tile, rem & 63u, &x, &y)) {
-              key = path_key(pp.seed, (uint64_t)y * pp.tm.width + x, (uint64_t)pp.first_sample + (rem >> 6));
-              camera_ray(pp.cam, x, y, key, o, dir);
-              thr = mk(1.0, 1.0, 1.0);
-              rad = mk(0.0, 0.0, 0.0);
-              depth = 0;
-              alive = true;
-            } else {
-              samples[path] = 0.0;
-              samples[pp.n_paths + path] = 0.0;
-              samples[2 * pp.n_paths + path] = 0.0;
-            }
+      unsigned long long need = __ballot(!alive);
+      while (need) {
+        if (local_next == local_end) {
+          unsigned long long base = 0;
+          if (lane == 0) base = atomicAdd(&counters[CNT_WORK], (unsigned long long)RT_WORK_BATCH);
+          base = __shfl(base, 0);
+          if (base >= pp.n_paths) {
+            exhausted = true;
+            break;
           }
+          local_next = (uint32_t)base;
+          local_end = (uint32_t)min(base + (unsigned long long)RT_WORK_BATCH, (unsigned long long)pp.n_paths);
         }
+        const uint32_t avail = local_end - local_next;
+        const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+        const bool mine = !alive && ((need >> lane) & 1ull) && rank < avail;
+        if (mine) {
+          path = local_next + rank;
+          thr = mk(1.0, 1.0, 1.0);
+          rad = mk(0.0, 0.0, 0.0);
+          depth = 0;
+          alive = start_path(pp, path, key, o, dir);
+          if (!alive) store_sample(samples, pp.n_paths, path, mk(0.0, 0.0, 0.0));
+        }
+        local_next += min(avail, (uint32_t)__popcll(need));
+        need &= ~__ballot(mine);
+        // lanes that drew a padding pixel need another index
+        need |= __ballot(mine && !alive);
       }
     }
     if (!__any(alive)) {
@@ -399,31 +471,189 @@ __global__ __launch_bounds__(RT_BLOCK) void k_paths(SceneK sc, PathParams pp, do
         finished = true;
       } else {
         if (COUNT) wc.shaded++;
-        shade_hit(sc, h, key, depth, o, dir, thr, rad);
+        const ShadeIn si = shade_input(h, o, dir);
+        shade_hit(sc, si, key, depth, o, dir, thr, rad);
         depth += 1;
         finished = depth > pp.max_depth;  // src/main.rs:818: deeper calls return black
       }
       if (finished) {
-        samples[path] = rad.x;
-        samples[pp.n_paths + path] = rad.y;
-        samples[2 * pp.n_paths + path] = rad.z;
+        store_sample(samples, pp.n_paths, path, rad);
         alive = false;
         n_done++;
       }
     }
   }
-  flush_counts(wc, counters, COUNT);
-  if (COUNT) {
-    unsigned long long v = n_done;
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-    if (lane == 0) atomicAdd(&counters[CNT_PATHS], v);
+  flush_counts(wc, counters, COUNT, n_done);
+}
+
+// ------------------------------------------------------------------------------------------
+// Wavefront form of the same loop: one launch per bounce over a compacted queue of the paths
+// that are still alive. Stage 0 starts every path of the launch (camera ray) and traces it;
+// stage 1 takes a queue of hits, shades each (all lanes have a hit, so the scatter code runs on
+// full waves), traces the scattered ray, and appends the survivors to the next queue with one
+// atomic per wave; stage 2 is stage 1 that keeps looping until its paths end, for the thin tail
+// of long paths. A path that misses adds throughput * sky and writes its sample; nothing else
+// is ever written twice, so results do not depend on queue order.
+//
+// A queue is n_seg segments of seg_cap records; segment s has its tail in counter line s.
+// Stage 0 block b appends to segment b % n_seg; later stages run on a (n_seg, blocks) grid whose
+// blockIdx.x is the segment they read AND append to, so a segment never outgrows its first
+// filling and concurrently running blocks spread over all tails.
+// ------------------------------------------------------------------------------------------
+struct alignas(16) QueueRec {  // 112 B
+  double hit_pos[3];
+  double dir[3];
+  double thr[3];
+  double u, v;
+  uint64_t key;
+  uint32_t path;
+  int32_t id;  // >= 0: triangle slot; < 0: ~sphere index
+  int32_t depth;
+  int32_t pad;
+};
+static_assert(sizeof(QueueRec) == 112, "QueueRec must be 112 bytes");
+
+struct QueueView {
+  QueueRec* recs;
+  double* rad;        // [entries][3], only when the scene has emitters
+  uint32_t seg_cap;   // records per segment
+  uint32_t tail_word; // CNT_Q0 or CNT_Q1: which word of a counter line holds this queue's tails
+};
+
+template <bool COUNT, int STAGE>
+__global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, QueueView in, QueueView out, uint32_t n_seg,
+                                                   double* __restrict__ samples, unsigned long long* counters) {
+  int32_t* stk = g_stack + threadIdx.x;
+  const int stride = blockDim.x;
+  const int lane = threadIdx.x & 63;
+  WorkCount wc{};
+  uint32_t n_done = 0;
+  uint32_t seg, n_in;
+  size_t entry = 0;
+  bool alive;
+  if (STAGE == 0) {
+    seg = blockIdx.x % n_seg;
+    n_in = pp.n_paths;
+    alive = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x < n_in;
+  } else {
+    seg = blockIdx.x;
+    n_in = (uint32_t)counters[(size_t)seg * RT_LINE_WORDS + in.tail_word];
+    const uint32_t i = blockIdx.y * RT_BLOCK + threadIdx.x;
+    alive = i < n_in;
+    entry = (size_t)seg * in.seg_cap + i;
   }
+  uint32_t path = 0;
+  uint64_t key = 0;
+  int depth = 0;
+  d3 o = mk(0, 0, 0), dir = mk(0, 0, 0), thr = mk(1, 1, 1), rad = mk(0, 0, 0);
+
+  if (alive) {
+    if (STAGE == 0) {
+      path = blockIdx.x * RT_BLOCK + threadIdx.x;
+      alive = start_path(pp, path, key, o, dir);
+      if (!alive) store_sample(samples, pp.n_paths, path, mk(0.0, 0.0, 0.0));
+    } else {
+      const QueueRec* r = in.recs + entry;
+      ShadeIn si;
+      si.hit_pos = mk(r->hit_pos[0], r->hit_pos[1], r->hit_pos[2]);
+      dir = mk(r->dir[0], r->dir[1], r->dir[2]);
+      thr = mk(r->thr[0], r->thr[1], r->thr[2]);
+      si.u = r->u;
+      si.v = r->v;
+      key = r->key;
+      path = r->path;
+      const int32_t id = r->id;
+      depth = r->depth;
+      si.slot = id >= 0 ? id : -1;
+      si.sphere = id >= 0 ? -1 : ~id;
+      if (sc.has_emission) rad = mk(in.rad[entry * 3], in.rad[entry * 3 + 1], in.rad[entry * 3 + 2]);
+      if (COUNT) wc.shaded++;
+      shade_hit(sc, si, key, depth, o, dir, thr, rad);
+      depth += 1;
+      if (depth > pp.max_depth) {  // src/main.rs:818
+        store_sample(samples, pp.n_paths, path, rad);
+        alive = false;
+        n_done++;
+      }
+    }
+  }
+
+  for (;;) {
+    HitK h;
+    h.slot = -1;
+    h.sphere = -1;
+    bool hit = false;
+    if (alive) {
+      wc.rays++;
+      trace_ray<COUNT>(sc, o, dir, stk, stride, h, wc);
+      hit = h.slot >= 0 || h.sphere >= 0;
+      if (!hit) {
+        const d3 s = sky(dir);  // src/main.rs:826
+        rad = rad + mk(thr.x * s.x, thr.y * s.y, thr.z * s.z);
+        store_sample(samples, pp.n_paths, path, rad);
+        alive = false;
+        n_done++;
+      }
+    }
+    if (STAGE == 2) {
+      if (!__any(alive)) break;
+      if (alive) {
+        if (COUNT) wc.shaded++;
+        const ShadeIn si = shade_input(h, o, dir);
+        shade_hit(sc, si, key, depth, o, dir, thr, rad);
+        depth += 1;
+        if (depth > pp.max_depth) {
+          store_sample(samples, pp.n_paths, path, rad);
+          alive = false;
+          n_done++;
+        }
+      }
+      continue;
+    }
+    // append the survivors to this block's segment: one atomic per wave
+    const unsigned long long mask = __ballot(hit);
+    if (mask) {
+      const int leader = __ffsll((long long)mask) - 1;
+      unsigned int base = 0;
+      if (lane == leader)
+        base = atomicAdd(reinterpret_cast<unsigned int*>(&counters[(size_t)seg * RT_LINE_WORDS + out.tail_word]), (unsigned int)__popcll(mask));
+      base = __shfl(base, leader);
+      if (hit) {
+        const size_t e = (size_t)seg * out.seg_cap + base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        QueueRec* r = out.recs + e;
+        const d3 hp = o + h.t * dir;  // src/main.rs:831
+        r->hit_pos[0] = hp.x;
+        r->hit_pos[1] = hp.y;
+        r->hit_pos[2] = hp.z;
+        r->dir[0] = dir.x;
+        r->dir[1] = dir.y;
+        r->dir[2] = dir.z;
+        r->thr[0] = thr.x;
+        r->thr[1] = thr.y;
+        r->thr[2] = thr.z;
+        r->u = h.u;
+        r->v = h.v;
+        r->key = key;
+        r->path = path;
+        r->id = h.slot >= 0 ? h.slot : ~h.sphere;
+        r->depth = depth;
+        r->pad = 0;
+        if (sc.has_emission) {
+          out.rad[e * 3] = rad.x;
+          out.rad[e * 3 + 1] = rad.y;
+          out.rad[e * 3 + 2] = rad.z;
+        }
+      }
+    }
+    break;
+  }
+  flush_counts(wc, counters, COUNT, n_done);
 }
 
 // Sums a pixel's samples in sample order (src/main.rs:1020-1024). `totals` carries the running
 // sum between launches when a call is split into several sample chunks. On the last chunk the
 // mean is added to the canvas (src/main.rs:1029-1037), or the plain sum to an f32 buffer.
-__global__ __launch_bounds__(RT_BLOCK) void k_resolve(TileMap tm, const double* __restrict__ samples, uint64_t n_paths, uint32_t spp,
+__global__ __launch_bounds__(RT_BLOCK) void k_resolve(TileMap tm, const double* __restrict__ samples, uint32_t n_paths, uint32_t spp,
                                                       double* __restrict__ totals, int first_chunk, int last_chunk, double divisor,
                                                       double* __restrict__ canvas, float* __restrict__ sum_f32) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // tile * 64 + pixel-in-tile
@@ -440,10 +670,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(TileMap tm, const double* 
   }
   const uint64_t base = (uint64_t)tile * spp * 64u + lp;
   for (uint32_t s = 0; s < spp; ++s) {
-    const uint64_t p = base + (uint64_t)s * 64u;
-    tr += samples[p];
-    tg += samples[n_paths + p];
-    tb += samples[2 * n_paths + p];
+    const double* p = samples + (base + (uint64_t)s * 64u) * 3u;
+    tr += p[0];
+    tg += p[1];
+    tb += p[2];
   }
   if (!last_chunk) {
     totals[i] = tr;
@@ -536,15 +766,35 @@ static TileMap make_tilemap(const rt_render_params* p) {
   return tm;
 }
 
-// Upper bound of the per-sample buffer; a call with more samples runs in chunks.
-static size_t sample_budget_bytes() {
-  const char* e = std::getenv("RT_SAMPLE_BUFFER_MIB");
-  size_t mib = 8192;
+static size_t env_mib(const char* name, size_t dflt) {
+  const char* e = std::getenv(name);
   if (e && *e) {
     long v = std::atol(e);
-    if (v > 0) mib = (size_t)v;
+    if (v > 0) return (size_t)v;
   }
-  return mib << 20;
+  return dflt;
+}
+
+static int event_at(DeviceScene* d, size_t i, hipEvent_t* out) {
+  while (d->ev_pool.size() <= i) {
+    hipEvent_t e;
+    HIP_TRY(hipEventCreate(&e));
+    d->ev_pool.push_back(e);
+  }
+  *out = d->ev_pool[i];
+  return RT_OK;
+}
+
+// Queue segments of a launch of n_paths paths: enough that concurrently running waves rarely
+// share a tail, few enough that a segment still feeds whole blocks.
+static uint32_t choose_segments(uint32_t n_paths) {
+  const uint32_t blocks = (n_paths + RT_BLOCK - 1) / RT_BLOCK;
+  return std::max<uint32_t>(1, std::min<uint32_t>(RT_SHARDS, blocks / 64));
+}
+static uint64_t queue_entries(uint32_t n_paths) {
+  const uint32_t blocks = (n_paths + RT_BLOCK - 1) / RT_BLOCK;
+  const uint32_t n_seg = choose_segments(n_paths);
+  return (uint64_t)n_seg * ((blocks + n_seg - 1) / n_seg) * RT_BLOCK;
 }
 
 static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas, float* d_sum, hipStream_t stream, const char* who) {
@@ -558,28 +808,89 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
   DeviceScene* d = s->dev;
   d->last_stream = stream;
   d->have_timing = false;
+  d->launches.clear();
   std::memset(&d->timing, 0, sizeof d->timing);
-  HIP_TRY(hipMemsetAsync(d->counters, 0, CNT_N * sizeof(unsigned long long), stream));
+  HIP_TRY(hipMemsetAsync(d->counters, 0, RT_COUNTER_BYTES, stream));
   if (p->spp == 0) return RT_OK;
 
   const TileMap tm = make_tilemap(p);
   if (tm.n_tiles == 0) return RT_OK;
-  const uint64_t n_pix = (uint64_t)tm.n_tiles * 64u;
-  const size_t budget = sample_budget_bytes();
-  uint32_t chunk = (uint32_t)std::min<uint64_t>(p->spp, std::max<uint64_t>(1, budget / (n_pix * 24u)));
-  const uint32_t n_chunks = (p->spp + chunk - 1) / chunk;
-  if ((rc = ensure_bytes((void**)&d->samples, &d->samples_bytes, (size_t)n_pix * chunk * 24u)) != RT_OK) return rc;
-  if (n_chunks > 1 && (rc = ensure_bytes((void**)&d->totals, &d->totals_bytes, (size_t)n_pix * 24u)) != RT_OK) return rc;
-
   const bool timing = (p->flags & RT_FLAG_TIMING) != 0;
   const bool count = (p->flags & RT_FLAG_COUNT_WORK) != 0;
+  const bool mega = (p->flags & (RT_FLAG_MEGAKERNEL | RT_FLAG_NO_REGEN)) != 0;
   const bool regen = (p->flags & RT_FLAG_NO_REGEN) == 0;
+  const bool emission = d->k.has_emission != 0;
+
+  // Work buffers are bounded (RT_WORK_BUFFER_MIB); a call that needs more runs in sample chunks.
+  const uint64_t n_pix = (uint64_t)tm.n_tiles * 64u;
+  const size_t per_path = 24u + (mega ? 0u : 2u * (sizeof(QueueRec) + (emission ? 24u : 0u)));
+  const size_t budget = env_mib("RT_WORK_BUFFER_MIB", 65536) << 20;
+  uint64_t chunk64 = std::max<uint64_t>(1, budget / (n_pix * per_path));
+  chunk64 = std::min<uint64_t>(chunk64, 0xfff00000ull / n_pix);
+  if (chunk64 == 0) {
+    rt_set_error("%s: image too large for one launch", who);
+    return RT_ERR_INVALID;
+  }
+  const uint32_t chunk = (uint32_t)std::min<uint64_t>(p->spp, chunk64);
+  const uint32_t n_chunks = (p->spp + chunk - 1) / chunk;
+  const uint64_t cap = n_pix * chunk;  // paths per launch
+  if ((rc = ensure_bytes((void**)&d->samples, &d->samples_bytes, (size_t)cap * 24u)) != RT_OK) return rc;
+  if (n_chunks > 1 && (rc = ensure_bytes((void**)&d->totals, &d->totals_bytes, (size_t)n_pix * 24u)) != RT_OK) return rc;
+  if (!mega) {
+    const uint64_t qe = queue_entries((uint32_t)cap);
+    for (int q = 0; q < 2; ++q) {
+      if ((rc = ensure_bytes(&d->queue[q], &d->queue_bytes[q], (size_t)qe * sizeof(QueueRec))) != RT_OK) return rc;
+      if (emission && (rc = ensure_bytes((void**)&d->queue_rad[q], &d->queue_rad_bytes[q], (size_t)qe * 24u)) != RT_OK) return rc;
+    }
+  }
+
   const size_t lds = stack_lds_bytes(d);
   const double divisor = (double)(p->spp_total ? p->spp_total : p->spp);
-
+  const uint32_t tail_threshold = (uint32_t)env_mib("RT_TAIL_THRESHOLD", 32768);
   int cus = 256;
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d->device);
-  float ms_paths = 0.f, ms_resolve = 0.f;
+  size_t n_events = 0;
+  CounterSums prev{}, now{};
+
+  // Launch log; with timing every launch is bracketed by two events of the pool.
+  struct Pending {
+    size_t log_index;
+    size_t ev0;
+  };
+  std::vector<Pending> pending;
+  auto begin_launch = [&](uint32_t kind, uint32_t items) -> int {
+    rt_launch_info li;
+    std::memset(&li, 0, sizeof li);
+    li.kind = kind;
+    li.items = items;
+    d->launches.push_back(li);
+    if (timing) {
+      hipEvent_t e;
+      int r = event_at(d, n_events, &e);
+      if (r != RT_OK) return r;
+      HIP_TRY(hipEventRecord(e, stream));
+      pending.push_back(Pending{d->launches.size() - 1, n_events});
+      n_events += 2;
+    }
+    return RT_OK;
+  };
+  auto end_launch = [&]() -> int {
+    HIP_TRY(hipGetLastError());
+    if (timing) {
+      hipEvent_t e;
+      int r = event_at(d, pending.back().ev0 + 1, &e);
+      if (r != RT_OK) return r;
+      HIP_TRY(hipEventRecord(e, stream));
+    }
+    return RT_OK;
+  };
+  auto account = [&](size_t log_index) {  // counters are cumulative over the call
+    rt_launch_info& li = d->launches[log_index];
+    li.rays = now.w[CNT_RAYS] - prev.w[CNT_RAYS];
+    li.node_visits = now.w[CNT_NODES] - prev.w[CNT_NODES];
+    li.tri_tests = now.w[CNT_TRIS] - prev.w[CNT_TRIS];
+    prev = now;
+  };
 
   for (uint32_t c = 0; c < n_chunks; ++c) {
     PathParams pp;
@@ -588,49 +899,93 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
     pp.seed = p->seed;
     pp.spp = std::min(chunk, p->spp - c * chunk);
     pp.first_sample = p->first_sample + c * chunk;
-    pp.n_paths = n_pix * pp.spp;
+    pp.n_paths = (uint32_t)(n_pix * pp.spp);
     pp.max_depth = p->max_depth;
-    const uint64_t blocks_all = (pp.n_paths + RT_BLOCK - 1) / RT_BLOCK;
-    if (blocks_all > 0x7fffffffull) {
-      rt_set_error("%s: too many paths in one launch; lower RT_SAMPLE_BUFFER_MIB", who);
-      return RT_ERR_INVALID;
-    }
-    uint32_t grid;
-    if (regen) {
-      grid = (uint32_t)std::min<uint64_t>(blocks_all, (uint64_t)cus * 8u);
-      HIP_TRY(hipMemsetAsync(d->counters + CNT_QUEUE, 0, sizeof(unsigned long long), stream));
+    const uint32_t blocks_all = (pp.n_paths + RT_BLOCK - 1) / RT_BLOCK;
+
+    if (mega) {
+      uint32_t grid = blocks_all;
+      if (regen) {
+        grid = std::min<uint32_t>(blocks_all, (uint32_t)cus * 8u);
+        HIP_TRY(hipMemsetAsync(d->counters + CNT_WORK, 0, sizeof(unsigned long long), stream));
+      }
+      if ((rc = begin_launch(3, pp.n_paths)) != RT_OK) return rc;
+      if (regen) {
+        if (count) hipLaunchKernelGGL((k_paths<true, true>), dim3(grid), dim3(RT_BLOCK), lds, stream, d->k, pp, d->samples, d->counters);
+        else hipLaunchKernelGGL((k_paths<false, true>), dim3(grid), dim3(RT_BLOCK), lds, stream, d->k, pp, d->samples, d->counters);
+      } else {
+        if (count) hipLaunchKernelGGL((k_paths<true, false>), dim3(grid), dim3(RT_BLOCK), lds, stream, d->k, pp, d->samples, d->counters);
+        else hipLaunchKernelGGL((k_paths<false, false>), dim3(grid), dim3(RT_BLOCK), lds, stream, d->k, pp, d->samples, d->counters);
+      }
+      if ((rc = end_launch()) != RT_OK) return rc;
     } else {
-      grid = (uint32_t)blocks_all;
+      // wavefront: stage 0 over all paths, then one launch per bounce over the survivors
+      const uint32_t n_seg = choose_segments(pp.n_paths);
+      const uint32_t seg_cap = ((blocks_all + n_seg - 1) / n_seg) * RT_BLOCK;
+      QueueView qv[2];
+      for (int q = 0; q < 2; ++q) qv[q] = QueueView{(QueueRec*)d->queue[q], d->queue_rad[q], seg_cap, (uint32_t)(q ? CNT_Q1 : CNT_Q0)};
+      // both tails of every line start at zero (two adjacent words per line)
+      HIP_TRY(hipMemset2DAsync(d->counters + CNT_Q0, RT_LINE_WORDS * sizeof(unsigned long long), 0, 2 * sizeof(unsigned long long), RT_SHARDS, stream));
+      if ((rc = begin_launch(0, pp.n_paths)) != RT_OK) return rc;
+      if (count) hipLaunchKernelGGL((k_wave<true, 0>), dim3(blocks_all), dim3(RT_BLOCK), lds, stream, d->k, pp, qv[0], qv[0], n_seg, d->samples, d->counters);
+      else hipLaunchKernelGGL((k_wave<false, 0>), dim3(blocks_all), dim3(RT_BLOCK), lds, stream, d->k, pp, qv[0], qv[0], n_seg, d->samples, d->counters);
+      if ((rc = end_launch()) != RT_OK) return rc;
+      int cur = 0;
+      for (;;) {
+        if ((rc = read_counters(d, stream, &now)) != RT_OK) return rc;
+        account(d->launches.size() - 1);
+        const int tail_word = cur ? CNT_Q1 : CNT_Q0;
+        const uint64_t n_in = now.w[tail_word];
+        if (n_in == 0) break;
+        uint32_t max_seg = 0;
+        for (uint32_t sgi = 0; sgi < n_seg; ++sgi)
+          max_seg = std::max<uint32_t>(max_seg, (uint32_t)d->host_counters[(size_t)sgi * RT_LINE_WORDS + tail_word]);
+        if (max_seg > seg_cap || n_in > pp.n_paths) {
+          rt_set_error("%s: internal error: a queue segment holds %u records, capacity %u", who, max_seg, seg_cap);
+          return RT_ERR_HIP;
+        }
+        const dim3 grid(n_seg, (max_seg + RT_BLOCK - 1) / RT_BLOCK);
+        const int nxt = cur ^ 1;
+        if (n_in <= tail_threshold) {
+          if ((rc = begin_launch(2, (uint32_t)n_in)) != RT_OK) return rc;
+          if (count) hipLaunchKernelGGL((k_wave<true, 2>), grid, dim3(RT_BLOCK), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, d->samples, d->counters);
+          else hipLaunchKernelGGL((k_wave<false, 2>), grid, dim3(RT_BLOCK), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, d->samples, d->counters);
+          if ((rc = end_launch()) != RT_OK) return rc;
+          if (count || timing) {
+            if ((rc = read_counters(d, stream, &now)) != RT_OK) return rc;
+            account(d->launches.size() - 1);
+          }
+          break;
+        }
+        HIP_TRY(hipMemset2DAsync(d->counters + (nxt ? CNT_Q1 : CNT_Q0), RT_LINE_WORDS * sizeof(unsigned long long), 0, sizeof(unsigned long long), RT_SHARDS, stream));
+        if ((rc = begin_launch(1, (uint32_t)n_in)) != RT_OK) return rc;
+        if (count) hipLaunchKernelGGL((k_wave<true, 1>), grid, dim3(RT_BLOCK), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, d->samples, d->counters);
+        else hipLaunchKernelGGL((k_wave<false, 1>), grid, dim3(RT_BLOCK), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, d->samples, d->counters);
+        if ((rc = end_launch()) != RT_OK) return rc;
+        cur = nxt;
+      }
     }
-    if (timing) HIP_TRY(hipEventRecord(d->ev[0], stream));
-    if (regen) {
-      if (count) hipLaunchKernelGGL((k_paths<true, true>), dim3(grid), dim3(RT_BLOCK), lds, stream, d->k, pp, d->samples, d->counters);
-      else hipLaunchKernelGGL((k_paths<false, true>), dim3(grid), dim3(RT_BLOCK), lds, stream, d->k, pp, d->samples, d->counters);
-    } else {
-      if (count) hipLaunchKernelGGL((k_paths<true, false>), dim3(grid), dim3(RT_BLOCK), lds, stream, d->k, pp, d->samples, d->counters);
-      else hipLaunchKernelGGL((k_paths<false, false>), dim3(grid), dim3(RT_BLOCK), lds, stream, d->k, pp, d->samples, d->counters);
-    }
-    HIP_TRY(hipGetLastError());
-    if (timing) HIP_TRY(hipEventRecord(d->ev[1], stream));
     const uint32_t rgrid = (uint32_t)((n_pix + RT_BLOCK - 1) / RT_BLOCK);
+    if ((rc = begin_launch(4, (uint32_t)n_pix)) != RT_OK) return rc;
     hipLaunchKernelGGL(k_resolve, dim3(rgrid), dim3(RT_BLOCK), 0, stream, tm, d->samples, pp.n_paths, pp.spp, d->totals,
                        (int)(c == 0), (int)(c + 1 == n_chunks), divisor, d_canvas, d_sum);
-    HIP_TRY(hipGetLastError());
-    if (timing) {
-      HIP_TRY(hipEventRecord(d->ev[2], stream));
-      HIP_TRY(hipEventSynchronize(d->ev[2]));
-      float a = 0.f, b = 0.f;
-      HIP_TRY(hipEventElapsedTime(&a, d->ev[0], d->ev[1]));
-      HIP_TRY(hipEventElapsedTime(&b, d->ev[1], d->ev[2]));
-      ms_paths += a;
-      ms_resolve += b;
-    }
+    if ((rc = end_launch()) != RT_OK) return rc;
   }
   if (timing) {
-    d->timing.ms_paths = ms_paths;
-    d->timing.ms_resolve = ms_resolve;
-    d->timing.path_launches = n_chunks;
-    d->timing.resolve_launches = n_chunks;
+    HIP_TRY(hipStreamSynchronize(stream));
+    for (const Pending& pe : pending) {
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, d->ev_pool[pe.ev0], d->ev_pool[pe.ev0 + 1]));
+      rt_launch_info& li = d->launches[pe.log_index];
+      li.ms = ms;
+      if (li.kind == 4) {
+        d->timing.ms_resolve += ms;
+        d->timing.resolve_launches++;
+      } else {
+        d->timing.ms_paths += ms;
+        d->timing.path_launches++;
+      }
+    }
     d->have_timing = true;
   }
   return RT_OK;
@@ -661,9 +1016,9 @@ extern "C" int rt_render_accumulate(rt_scene* s, const rt_render_params* p, doub
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(canvas, d->stage, bytes, hipMemcpyDeviceToHost));
   if (rays_out) {
-    unsigned long long c[CNT_N];
-    HIP_TRY(hipMemcpy(c, d->counters, sizeof c, hipMemcpyDeviceToHost));
-    *rays_out = c[CNT_RAYS];
+    CounterSums cs;
+    if ((rc = read_counters(d, nullptr, &cs)) != RT_OK) return rc;
+    *rays_out = cs.w[CNT_RAYS];
   }
   return RT_OK;
 }
@@ -688,7 +1043,7 @@ extern "C" int rt_trace(rt_scene* s, const double* org3, const double* dir3, siz
   rt_hit* d_hit = (rt_hit*)(d_dir + n * 3);
   HIP_TRY(hipMemcpy(d_org, org3, ray_bytes, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(d_dir, dir3, ray_bytes, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemset(d->counters, 0, CNT_N * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(d->counters, 0, RT_COUNTER_BYTES));
   const uint32_t grid = (uint32_t)((n + RT_BLOCK - 1) / RT_BLOCK);
   hipLaunchKernelGGL((k_trace<true>), dim3(grid), dim3(RT_BLOCK), stack_lds_bytes(d), nullptr, d->k, d_org, d_dir, n, d_hit, d->counters);
   HIP_TRY(hipGetLastError());
@@ -719,7 +1074,7 @@ extern "C" int rt_primary_hits(rt_scene* s, const rt_render_params* p, int32_t* 
   q.flags |= RT_FLAG_NO_JITTER;
   q.dof_strength = 0.0;
   CameraK cam = make_camera(&q);
-  HIP_TRY(hipMemset(d->counters, 0, CNT_N * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(d->counters, 0, RT_COUNTER_BYTES));
   const uint32_t grid = (uint32_t)((npix + RT_BLOCK - 1) / RT_BLOCK);
   hipLaunchKernelGGL(k_primary, dim3(grid), dim3(RT_BLOCK), stack_lds_bytes(d), nullptr, d->k, cam, d_obj, d_tri, d_t, d_u, d_v, d->counters);
   HIP_TRY(hipGetLastError());
@@ -744,15 +1099,15 @@ extern "C" int rt_scene_last_stats(rt_scene* s, rt_stats* out) {
   }
   DeviceScene* d = s->dev;
   HIP_TRY(hipSetDevice(d->device));
-  HIP_TRY(hipStreamSynchronize(d->last_stream));
-  unsigned long long c[CNT_N];
-  HIP_TRY(hipMemcpy(c, d->counters, sizeof c, hipMemcpyDeviceToHost));
-  out->rays = c[CNT_RAYS];
-  out->node_visits = c[CNT_NODES];
-  out->tri_tests = c[CNT_TRIS];
-  out->sphere_tests = c[CNT_SPHERES];
-  out->shaded_hits = c[CNT_SHADED];
-  out->paths = c[CNT_PATHS];
+  CounterSums cs;
+  int rc = read_counters(d, d->last_stream, &cs);
+  if (rc != RT_OK) return rc;
+  out->rays = cs.w[CNT_RAYS];
+  out->node_visits = cs.w[CNT_NODES];
+  out->tri_tests = cs.w[CNT_TRIS];
+  out->sphere_tests = cs.w[CNT_SPHERES];
+  out->shaded_hits = cs.w[CNT_SHADED];
+  out->paths = cs.w[CNT_PATHS];
   return RT_OK;
 }
 
@@ -766,5 +1121,20 @@ extern "C" int rt_scene_last_timing(rt_scene* s, rt_timing* out) {
     return RT_ERR_INVALID;
   }
   *out = s->dev->timing;
+  return RT_OK;
+}
+
+extern "C" int rt_scene_last_launches(rt_scene* s, rt_launch_info* out, uint32_t capacity, uint32_t* n_out) {
+  if (!s || !n_out || (capacity && !out)) {
+    rt_set_error("rt_scene_last_launches: null argument");
+    return RT_ERR_INVALID;
+  }
+  if (!s->dev) {
+    rt_set_error("rt_scene_last_launches: the scene has not been uploaded");
+    return RT_ERR_NO_DEVICE;
+  }
+  const std::vector<rt_launch_info>& l = s->dev->launches;
+  *n_out = (uint32_t)l.size();
+  for (uint32_t i = 0; i < capacity && i < l.size(); ++i) out[i] = l[i];
   return RT_OK;
 }

@@ -100,6 +100,7 @@ struct SceneK {
   const TextureRec* tex;
   int32_t root_ref;
   uint32_t n_spheres;
+  uint32_t has_emission;  // some material has a non-zero emission
 };
 
 struct HitK {
@@ -328,13 +329,20 @@ __device__ __forceinline__ double powi5(double a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// raytrace's hit branch. Returns false when the path ends here (never for a hit: the path
-// continues until a miss or the depth cap), fills the next ray and updates throughput/radiance.
+// raytrace's hit branch (a hit never ends a path: it continues until a miss or the depth cap):
+// fills the next ray and updates throughput and emitted radiance.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void shade_hit(const SceneK& sc, const HitK& h, const uint64_t key, const int depth, d3& o,
+struct ShadeIn {
+  d3 hit_pos;      // origin + distance * dir, src/main.rs:831
+  double u, v;     // barycentrics (mesh hits)
+  int32_t slot;    // leaf-order triangle slot, or -1
+  int32_t sphere;  // sphere record index, or -1
+};
+
+__device__ __forceinline__ void shade_hit(const SceneK& sc, const ShadeIn& h, const uint64_t key, const int depth, d3& o,
                                           d3& dir, d3& thr, d3& rad) {
   const double eps = 0.00000001;
-  const d3 hit_pos = o + h.t * dir;  // src/main.rs:831
+  const d3 hit_pos = h.hit_pos;
   d3 normal;
   double tex_u = 0.0, tex_v = 1.0;  // src/main.rs:490
   int32_t obj;
@@ -393,14 +401,40 @@ __device__ __forceinline__ void shade_hit(const SceneK& sc, const HitK& h, const
       r = 2.0 * cdn * normal - camera_dir;
     }
     const d3 reflected_camera = normalize(r);
-    const d3 jit = metallic * random_unit_sphere_surface(rng);  // src/main.rs:869
-    rng.skip(3);                                                // src/main.rs:871-873, unused draws
+    // src/main.rs:869-883 as ONE loop. The reference draws a Marsaglia point for the metal jitter
+    // (rejection loop 265-278), three unused uniforms (871-873), then Marsaglia points until one
+    // lies in the normal's hemisphere (876-883). Nested rejection loops cost a wave the maximum
+    // trip count of every level; this state machine consumes exactly the same draws in the same
+    // order, one pair per iteration, so a wave pays only the longest total.
+    d3 jit = mk(0.0, 0.0, 0.0);
     d3 diffuse_out = mk(0.0, 0.0, 0.0);
-    for (int tries = 0; tries < RT_REJECT_CAP; ++tries) {  // src/main.rs:876-883
-      const d3 rs = random_unit_sphere_surface(rng);
-      if (dot(rs, normal) > 0.0) {
-        diffuse_out = rs;
-        break;
+    {
+      int phase = 0, inner = 0, outer = 0;
+      for (;;) {
+        const double x1 = rng.range(-1.0, 1.0);
+        const double x2 = rng.range(-1.0, 1.0);
+        inner += 1;
+        const double r2 = x1 * x1 + x2 * x2;
+        const bool accept = !(r2 >= 1.0);
+        if (!accept && inner < RT_REJECT_CAP) continue;
+        d3 pt = mk(0.0, 0.0, 1.0);  // fallback after RT_REJECT_CAP rejections
+        if (accept) {
+          const double sq = sqrt(1.0 - x1 * x1 - x2 * x2);
+          pt = mk(2.0 * x1 * sq, 2.0 * x2 * sq, 1.0 - 2.0 * (x1 * x1 + x2 * x2));
+        }
+        inner = 0;
+        if (phase == 0) {
+          jit = metallic * pt;
+          rng.skip(3);
+          phase = 1;
+        } else {
+          outer += 1;
+          if (dot(pt, normal) > 0.0) {
+            diffuse_out = pt;
+            break;
+          }
+          if (outer >= RT_REJECT_CAP) break;
+        }
       }
     }
     diffuse_out = diffuse * diffuse_out + normal;  // src/main.rs:884

@@ -260,6 +260,13 @@ class Scene:
         check(lib.rt_scene_last_stats(self._h, C.byref(s)), "rt_scene_last_stats")
         return s
 
+    def last_launches(self):
+        n = C.c_uint32()
+        check(lib.rt_scene_last_launches(self._h, None, 0, C.byref(n)), "rt_scene_last_launches")
+        out = (_ffi.rt_launch_info * max(1, n.value))()
+        check(lib.rt_scene_last_launches(self._h, out, n.value, C.byref(n)), "rt_scene_last_launches")
+        return [out[i] for i in range(n.value)]
+
     def last_timing(self):
         t = _ffi.rt_timing()
         check(lib.rt_scene_last_timing(self._h, C.byref(t)), "rt_scene_last_timing")

@@ -181,7 +181,8 @@ def test_render_variants_are_bitwise_identical(gpu_scenes, monkeypatch):
     w, h, spp = 72, 40, 5
     base = np.zeros((h, w, 3))
     rays = s.render(base, rt.render_params(width=w, height=h, spp=spp, seed=5))
-    for flags in (_ffi.RT_FLAG_NO_REGEN, _ffi.RT_FLAG_COUNT_WORK, _ffi.RT_FLAG_NO_REGEN | _ffi.RT_FLAG_COUNT_WORK, _ffi.RT_FLAG_TIMING):
+    for flags in (_ffi.RT_FLAG_NO_REGEN, _ffi.RT_FLAG_COUNT_WORK, _ffi.RT_FLAG_NO_REGEN | _ffi.RT_FLAG_COUNT_WORK, _ffi.RT_FLAG_TIMING,
+                  _ffi.RT_FLAG_MEGAKERNEL, _ffi.RT_FLAG_MEGAKERNEL | _ffi.RT_FLAG_COUNT_WORK, _ffi.RT_FLAG_TIMING | _ffi.RT_FLAG_COUNT_WORK):
         c = np.zeros((h, w, 3))
         assert s.render(c, rt.render_params(width=w, height=h, spp=spp, seed=5, flags=flags)) == rays
         assert c.tobytes() == base.tobytes(), flags
@@ -190,11 +191,44 @@ def test_render_variants_are_bitwise_identical(gpu_scenes, monkeypatch):
     s.render(c, rt.render_params(width=w, height=h, spp=spp, seed=5, flags=_ffi.RT_FLAG_COUNT_WORK))
     st = s.last_stats()
     assert st.rays == rays and st.paths == w * h * spp and st.node_visits > st.rays and st.shaded_hits < st.rays
-    monkeypatch.setenv("RT_SAMPLE_BUFFER_MIB", "1")  # forces several sample chunks
-    c = np.zeros((h, w, 3))
+    # the wavefront form's launch log: first bounce over every path, then shrinking queues
+    log = s.last_launches()
+    assert log[0].kind == 0 and log[0].items == ((w + 7) // 8) * ((h + 7) // 8) * 64 * spp
+    assert log[-1].kind == 4 and sum(l.rays for l in log) == rays
+    assert all(a.items > b.items for a, b in zip(log[:-1], log[1:-1]))
     s2 = scenes.build("spot")
-    assert s2.render(c, rt.render_params(width=w, height=h, spp=spp, seed=5)) == rays
-    assert c.tobytes() == base.tobytes()
+    for env in ({"RT_WORK_BUFFER_MIB": "1"},          # several sample chunks
+                {"RT_TAIL_THRESHOLD": "1"},           # (almost) never switch to the looping tail kernel
+                {"RT_TAIL_THRESHOLD": "100000000"}):  # tail kernel right after the first bounce
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for flags in (0, _ffi.RT_FLAG_MEGAKERNEL):
+            c = np.zeros((h, w, 3))
+            assert s2.render(c, rt.render_params(width=w, height=h, spp=spp, seed=5, flags=flags)) == rays
+            assert c.tobytes() == base.tobytes(), (env, flags)
+        for k in env:
+            monkeypatch.delenv(k)
+
+
+def test_emissive_materials(oracle):
+    """Emission travels with the path (src/main.rs:925-929): an emissive floor under a grey sphere
+    and a glass sphere, every scheduling form against the oracle."""
+    floor = rt.Opaque((0.8, 0.7, 0.6), 0.0, 1.0, 0.0, emission=(0.3, 0.2, 0.1))
+    ball = rt.Opaque((0.5, 0.5, 0.9), 0.2, 0.8, 0.5, emission=(0.0, 0.1, 0.4))
+    glass = rt.Dielectric(1.5)
+    tv = np.array([[[30, -0.7, -30], [-30, -0.7, -30], [0, -0.7, 5]]], dtype=np.float64)
+    tn = np.tile(np.array([0, 1.0, 0]), (1, 3, 1)); tuv = np.zeros((1, 3, 2))
+    args = ([_ffi.RT_OBJ_MESH, _ffi.RT_OBJ_SPHERE, _ffi.RT_OBJ_SPHERE], [floor, ball, glass], tv, tn, tuv, [0], [0],
+            [[0.5, 0, -3, 0.7], [-0.7, -0.2, -2.2, 0.5]], [1, 2])
+    s = rt.Scene.from_desc(*args)
+    o = oracle.OracleScene.from_desc_arrays(*args)
+    w, h, spp = 64, 48, 4
+    oc = np.zeros((h, w, 3))
+    orays, _ = o.render(oc, rt.render_params(width=w, height=h, spp=spp, seed=6))
+    for flags in (0, _ffi.RT_FLAG_MEGAKERNEL, _ffi.RT_FLAG_NO_REGEN):
+        c = np.zeros((h, w, 3))
+        assert s.render(c, rt.render_params(width=w, height=h, spp=spp, seed=6, flags=flags)) == orays
+        assert rel_err(c, oc) < IMG_RTOL, flags
 
 
 def test_tile_split_union_equals_whole(gpu_scenes):

@@ -146,6 +146,12 @@ typedef struct rt_stats {
   uint64_t sphere_tests;
   uint64_t shaded_hits;   /* hits whose shading record was fetched         */
   uint64_t paths;
+  /* Divergence accounting (RT_FLAG_COUNT_WORK): waves that ran, and how many iterations of
+   * each per-lane loop the waves executed (a wave runs a loop as long as its slowest lane). */
+  uint64_t waves;
+  uint64_t wave_iters_inner;  /* traversal steps                     */
+  uint64_t wave_iters_leaf;   /* triangle tests                      */
+  uint64_t wave_iters_reject; /* scatter-direction rejection sampling */
 } rt_stats;
 
 /* Durations of the last call made with RT_FLAG_TIMING, measured with HIP events on the
@@ -167,6 +173,10 @@ typedef struct rt_launch_info {
   uint64_t rays;        /* nearest-hit queries the launch made                                   */
   uint64_t node_visits; /* RT_FLAG_COUNT_WORK                                                   */
   uint64_t tri_tests;   /* RT_FLAG_COUNT_WORK                                                   */
+  uint64_t waves;             /* RT_FLAG_COUNT_WORK; see rt_stats                                */
+  uint64_t wave_iters_inner;
+  uint64_t wave_iters_leaf;
+  uint64_t wave_iters_reject;
 } rt_launch_info;
 
 typedef struct rt_mesh rt_mesh;       /* PolygonMesh, src/main.rs:566-574 */

@@ -159,7 +159,7 @@ bool intersects_sphere(const Vec3& center, double radius, const Vec3& orig, cons
 // draw counter: stage 0 is the camera (src/main.rs:995-1008), stage d+1 is the shading of the
 // hit found at recursion depth d (src/main.rs:859-883, 956). A draw is
 //   mix64(key + GOLDEN * ((stage << 20) + index + 1))
-// with the splitmix64 finaliser as mix64, mapped to [0,1) with 53 bits.
+// with the splitmix64 finaliser as mix64, mapped to [0,1) with 52 bits.
 const uint64_t GOLDEN = 0x9e3779b97f4a7c15ull;
 const int REJECT_CAP = 64;  // tries per rejection loop before the defined fallback
 
@@ -189,7 +189,11 @@ struct Rng {
   double u01() {
     uint64_t z = mix64(key + GOLDEN * (stage_base + (uint64_t)index + 1));
     index += 1;
-    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+    // 52 random bits as the mantissa of a double in [1,2), minus 1 (as rand's f64 sampling does)
+    uint64_t bits = 0x3ff0000000000000ull | (z >> 12);
+    double d;
+    std::memcpy(&d, &bits, 8);
+    return d - 1.0;
   }
   // rng.gen_range(lo..hi) / gen_range(lo..=hi) — uniform on the interval.
   double range(double lo, double hi) { return lo + (hi - lo) * u01(); }
@@ -1154,16 +1158,16 @@ void bvh_trace(const uint32_t* node_words, uint32_t n_nodes, int32_t root_ref, c
                const std::vector<FlatTriangle>& tris, const Vec3& origin, const Vec3& dir, double* best_t,
                double* best_u, double* best_v, int64_t* best_flat, BvhCounts* counts) {
   const float K_FAR = 1.0f + 9.5367431640625e-07f;  // 1 + 2^-20
-  float o_lo[3], o_hi[3], inv[3];
+  float m_lo[3], m_hi[3], inv[3];
   double omax = std::fmax(std::fabs(origin.c[0]), std::fmax(std::fabs(origin.c[1]), std::fabs(origin.c[2])));
-  float pad = f32_up(omax * 2.384185791015625e-07);  // 2^-22
+  float pad = f32_up(omax * 4.76837158203125e-07);  // 2^-21
   for (int k = 0; k < 3; ++k) {
     float o32 = (float)origin.c[k];
-    o_lo[k] = o32 - pad;
-    o_hi[k] = o32 + pad;
     double d = dir.c[k];
     if (std::fabs(d) < 1e-30) d = std::signbit(d) ? -1e-30 : 1e-30;
     inv[k] = (float)(1.0 / d);
+    m_lo[k] = -(o32 - pad) * inv[k];
+    m_hi[k] = -(o32 + pad) * inv[k];
   }
   *best_t = std::numeric_limits<double>::infinity();
   *best_flat = -1;
@@ -1187,8 +1191,8 @@ void bvh_trace(const uint32_t* node_words, uint32_t n_nodes, int32_t root_ref, c
         float tnear = 0.0f, tfar = INFINITY;
         for (int k = 0; k < 3; ++k) {
           float bmin = f(n[k * 4 + c * 2 + 0]), bmax = f(n[k * 4 + c * 2 + 1]);
-          float ta = (bmin - o_hi[k]) * inv[k];
-          float tb = (bmax - o_lo[k]) * inv[k];
+          float ta = std::fmaf(bmin, inv[k], m_hi[k]);
+          float tb = std::fmaf(bmax, inv[k], m_lo[k]);
           tnear = std::fmax(tnear, std::fmin(ta, tb));
           tfar = std::fmin(tfar, std::fmax(ta, tb));
         }

@@ -110,6 +110,10 @@ class rt_stats(C.Structure):
         ("sphere_tests", C.c_uint64),
         ("shaded_hits", C.c_uint64),
         ("paths", C.c_uint64),
+        ("waves", C.c_uint64),
+        ("wave_iters_inner", C.c_uint64),
+        ("wave_iters_leaf", C.c_uint64),
+        ("wave_iters_reject", C.c_uint64),
     ]
 
 
@@ -131,6 +135,10 @@ class rt_launch_info(C.Structure):
         ("rays", C.c_uint64),
         ("node_visits", C.c_uint64),
         ("tri_tests", C.c_uint64),
+        ("waves", C.c_uint64),
+        ("wave_iters_inner", C.c_uint64),
+        ("wave_iters_leaf", C.c_uint64),
+        ("wave_iters_reject", C.c_uint64),
     ]
 
 

@@ -42,7 +42,7 @@ using namespace rtk;
 #define RT_LINE_WORDS 16   /* 64-bit words per line (128 B)                             */
 #define RT_WORK_BATCH 1024 /* path indices a wave takes from the work counter at a time */
 // words of a line
-enum { CNT_RAYS = 0, CNT_NODES, CNT_TRIS, CNT_SPHERES, CNT_SHADED, CNT_PATHS, CNT_Q0, CNT_Q1, CNT_WORK, CNT_N };
+enum { CNT_RAYS = 0, CNT_NODES, CNT_TRIS, CNT_SPHERES, CNT_SHADED, CNT_PATHS, CNT_Q0, CNT_Q1, CNT_WORK, CNT_WI_INNER, CNT_WI_LEAF, CNT_WI_REJECT, CNT_WAVES, CNT_N };
 #define RT_COUNTER_BYTES ((size_t)RT_SHARDS * RT_LINE_WORDS * sizeof(unsigned long long))
 
 struct DeviceScene {
@@ -281,6 +281,13 @@ __device__ __forceinline__ void flush_counts(const WorkCount& wc, unsigned long 
       if (e) atomicAdd(&line[CNT_SHADED], e);
       if (f) atomicAdd(&line[CNT_PATHS], f);
     }
+    const unsigned long long g = wave_sum(wc.wi_inner), h = wave_sum(wc.wi_leaf), i = wave_sum(wc.wi_reject);
+    if ((threadIdx.x & 63) == 0) {
+      if (g) atomicAdd(&line[CNT_WI_INNER], g);
+      if (h) atomicAdd(&line[CNT_WI_LEAF], h);
+      if (i) atomicAdd(&line[CNT_WI_REJECT], i);
+      atomicAdd(&line[CNT_WAVES], 1ull);
+    }
   }
 }
 
@@ -472,7 +479,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_paths(SceneK sc, PathParams pp, do
       } else {
         if (COUNT) wc.shaded++;
         const ShadeIn si = shade_input(h, o, dir);
-        shade_hit(sc, si, key, depth, o, dir, thr, rad);
+        shade_hit<COUNT>(sc, si, key, depth, o, dir, thr, rad, wc);
         depth += 1;
         finished = depth > pp.max_depth;  // src/main.rs:818: deeper calls return black
       }
@@ -568,7 +575,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
       si.sphere = id >= 0 ? -1 : ~id;
       if (sc.has_emission) rad = mk(in.rad[entry * 3], in.rad[entry * 3 + 1], in.rad[entry * 3 + 2]);
       if (COUNT) wc.shaded++;
-      shade_hit(sc, si, key, depth, o, dir, thr, rad);
+      shade_hit<COUNT>(sc, si, key, depth, o, dir, thr, rad, wc);
       depth += 1;
       if (depth > pp.max_depth) {  // src/main.rs:818
         store_sample(samples, pp.n_paths, path, rad);
@@ -600,7 +607,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
       if (alive) {
         if (COUNT) wc.shaded++;
         const ShadeIn si = shade_input(h, o, dir);
-        shade_hit(sc, si, key, depth, o, dir, thr, rad);
+        shade_hit<COUNT>(sc, si, key, depth, o, dir, thr, rad, wc);
         depth += 1;
         if (depth > pp.max_depth) {
           store_sample(samples, pp.n_paths, path, rad);
@@ -889,6 +896,10 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
     li.rays = now.w[CNT_RAYS] - prev.w[CNT_RAYS];
     li.node_visits = now.w[CNT_NODES] - prev.w[CNT_NODES];
     li.tri_tests = now.w[CNT_TRIS] - prev.w[CNT_TRIS];
+    li.waves = now.w[CNT_WAVES] - prev.w[CNT_WAVES];
+    li.wave_iters_inner = now.w[CNT_WI_INNER] - prev.w[CNT_WI_INNER];
+    li.wave_iters_leaf = now.w[CNT_WI_LEAF] - prev.w[CNT_WI_LEAF];
+    li.wave_iters_reject = now.w[CNT_WI_REJECT] - prev.w[CNT_WI_REJECT];
     prev = now;
   };
 
@@ -1108,6 +1119,10 @@ extern "C" int rt_scene_last_stats(rt_scene* s, rt_stats* out) {
   out->sphere_tests = cs.w[CNT_SPHERES];
   out->shaded_hits = cs.w[CNT_SHADED];
   out->paths = cs.w[CNT_PATHS];
+  out->waves = cs.w[CNT_WAVES];
+  out->wave_iters_inner = cs.w[CNT_WI_INNER];
+  out->wave_iters_leaf = cs.w[CNT_WI_LEAF];
+  out->wave_iters_reject = cs.w[CNT_WI_REJECT];
   return RT_OK;
 }
 

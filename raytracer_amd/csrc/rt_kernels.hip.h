@@ -44,7 +44,7 @@ __device__ __forceinline__ d3 normalize(d3 a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// counter-based generator: draw = mix64(key + GOLDEN * ((stage << 20) + index + 1)), 53 bits
+// counter-based generator: draw = mix64(key + GOLDEN * ((stage << 20) + index + 1)), 52 bits
 // ------------------------------------------------------------------------------------------
 #define RT_GOLDEN 0x9e3779b97f4a7c15ull
 
@@ -67,7 +67,8 @@ struct Rng {
   __device__ __forceinline__ void start(uint64_t key, uint32_t stage) { x = key + RT_GOLDEN * ((uint64_t)stage << 20); }
   __device__ __forceinline__ double u01() {
     x += RT_GOLDEN;
-    return (double)(mix64(x) >> 11) * (1.0 / 9007199254740992.0);
+    // 52 random bits as the mantissa of a double in [1,2), minus 1 (what rand's f64 sampling does)
+    return __longlong_as_double((long long)(0x3ff0000000000000ull | (mix64(x) >> 12))) - 1.0;
   }
   __device__ __forceinline__ double range(double lo, double hi) { return lo + (hi - lo) * u01(); }
   __device__ __forceinline__ void skip(uint32_t n) { x += RT_GOLDEN * (uint64_t)n; }
@@ -111,15 +112,25 @@ struct HitK {
 
 struct WorkCount {
   uint32_t rays, nodes, tris, spheres, shaded;
+  // loop iterations as the WAVE executes them (counted by the first active lane of each
+  // iteration): the divergence cost of the per-lane loops
+  uint32_t wi_inner, wi_leaf, wi_reject;
 };
+
+__device__ __forceinline__ bool first_active_lane() {
+  const unsigned long long m = __ballot(1);
+  return (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1;
+}
 
 // ------------------------------------------------------------------------------------------
 // Scene::hit
 // ------------------------------------------------------------------------------------------
 // Box culling in f32 that can only err towards visiting: the ray origin is widened by `pad`
-// (>= its f32 rounding error), the far distance is scaled up by (1 + 2^-20), and the
-// pruning distance is the hit distance rounded up to f32 and scaled the same way; the boxes
-// themselves were rounded outward and padded by the builder.
+// (2^-21 of its magnitude: its f32 rounding, the rounding of o -+ pad, and the rounding of the
+// product folded into the fused multiply-add each cost at most 2^-24), the far distance is
+// scaled up by (1 + 2^-20) against the f32 rounding of the reciprocal direction and of the
+// fused operation itself, and the pruning distance is the hit distance rounded up to f32 and
+// scaled the same way; the boxes themselves were rounded outward and padded by the builder.
 #define RT_K_FAR 1.00000095367431640625f /* 1 + 2^-20 */
 
 __device__ __forceinline__ float f32_up(double x) {
@@ -134,22 +145,24 @@ __device__ __forceinline__ void trace_ray(const SceneK& sc, const d3 o, const d3
   double best_u = 0.0, best_v = 0.0;
   int32_t best_slot = -1, best_flat = 0x7fffffff;
 
-  // culling ray
+  // culling ray: t = b * inv - (o -+ pad) * inv, one fused operation per plane (culling only;
+  // the fused rounding perturbs the padded origin by less than the pad already allows for)
   const double omax = fmax(fabs(o.x), fmax(fabs(o.y), fabs(o.z)));
-  const float pad = f32_up(omax * 2.384185791015625e-07);  // 2^-22
+  const float pad = f32_up(omax * 4.76837158203125e-07);  // 2^-21
   const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
-  const float ox_lo = ox - pad, ox_hi = ox + pad;
-  const float oy_lo = oy - pad, oy_hi = oy + pad;
-  const float oz_lo = oz - pad, oz_hi = oz + pad;
   double dx = d.x, dy = d.y, dz = d.z;
   if (fabs(dx) < 1e-30) dx = signbit(dx) ? -1e-30 : 1e-30;
   if (fabs(dy) < 1e-30) dy = signbit(dy) ? -1e-30 : 1e-30;
   if (fabs(dz) < 1e-30) dz = signbit(dz) ? -1e-30 : 1e-30;
   const float ix = (float)(1.0 / dx), iy = (float)(1.0 / dy), iz = (float)(1.0 / dz);
+  // for a box's min plane use o + pad, for its max plane o - pad (pads the box, whatever the sign)
+  const float mx_lo = -(ox - pad) * ix, mx_hi = -(ox + pad) * ix;
+  const float my_lo = -(oy - pad) * iy, my_hi = -(oy + pad) * iy;
+  const float mz_lo = -(oz - pad) * iz, mz_hi = -(oz + pad) * iz;
   float best32k = __int_as_float(0x7f800000);
 
-  int sp = 0;
-  stk[0] = RT_REF_SENTINEL;
+  int32_t* sp = stk;  // top of this lane's stack (entries are `stride` ints apart)
+  *sp = RT_REF_SENTINEL;
   int32_t cur = sc.root_ref;
 
   for (;;) {
@@ -157,32 +170,37 @@ __device__ __forceinline__ void trace_ray(const SceneK& sc, const d3 o, const d3
       const float4* np = reinterpret_cast<const float4*>(sc.nodes + cur);
       const float4 bx = np[0], by = np[1], bz = np[2];
       const int4 ch = reinterpret_cast<const int4*>(np)[3];
-      if (COUNT) wc.nodes++;
-      // child 0
+      if (COUNT) {
+        wc.nodes++;
+        if (first_active_lane()) wc.wi_inner++;
+      }
+      // A NaN plane distance (inf - inf when a direction component is zero and the numbers are
+      // huge) drops out of fminf/fmaxf, which then ignore that plane: still conservative.
       float ta, tb, tn0, tf0, tn1, tf1;
-      ta = (bx.x - ox_hi) * ix;
-      tb = (bx.y - ox_lo) * ix;
+      // child 0
+      ta = __builtin_fmaf(bx.x, ix, mx_hi);
+      tb = __builtin_fmaf(bx.y, ix, mx_lo);
       tn0 = fminf(ta, tb);
       tf0 = fmaxf(ta, tb);
-      ta = (by.x - oy_hi) * iy;
-      tb = (by.y - oy_lo) * iy;
+      ta = __builtin_fmaf(by.x, iy, my_hi);
+      tb = __builtin_fmaf(by.y, iy, my_lo);
       tn0 = fmaxf(tn0, fminf(ta, tb));
       tf0 = fminf(tf0, fmaxf(ta, tb));
-      ta = (bz.x - oz_hi) * iz;
-      tb = (bz.y - oz_lo) * iz;
+      ta = __builtin_fmaf(bz.x, iz, mz_hi);
+      tb = __builtin_fmaf(bz.y, iz, mz_lo);
       tn0 = fmaxf(fmaxf(tn0, fminf(ta, tb)), 0.0f);
       tf0 = fminf(tf0, fmaxf(ta, tb)) * RT_K_FAR;
       // child 1
-      ta = (bx.z - ox_hi) * ix;
-      tb = (bx.w - ox_lo) * ix;
+      ta = __builtin_fmaf(bx.z, ix, mx_hi);
+      tb = __builtin_fmaf(bx.w, ix, mx_lo);
       tn1 = fminf(ta, tb);
       tf1 = fmaxf(ta, tb);
-      ta = (by.z - oy_hi) * iy;
-      tb = (by.w - oy_lo) * iy;
+      ta = __builtin_fmaf(by.z, iy, my_hi);
+      tb = __builtin_fmaf(by.w, iy, my_lo);
       tn1 = fmaxf(tn1, fminf(ta, tb));
       tf1 = fminf(tf1, fmaxf(ta, tb));
-      ta = (bz.z - oz_hi) * iz;
-      tb = (bz.w - oz_lo) * iz;
+      ta = __builtin_fmaf(bz.z, iz, mz_hi);
+      tb = __builtin_fmaf(bz.w, iz, mz_lo);
       tn1 = fmaxf(fmaxf(tn1, fminf(ta, tb)), 0.0f);
       tf1 = fminf(tf1, fmaxf(ta, tb)) * RT_K_FAR;
 
@@ -192,16 +210,16 @@ __device__ __forceinline__ void trace_ray(const SceneK& sc, const d3 o, const d3
         const bool swap = tn1 < tn0;
         const int32_t near = swap ? ch.y : ch.x;
         const int32_t far = swap ? ch.x : ch.y;
-        sp += 1;
-        stk[sp * stride] = far;
+        sp += stride;
+        *sp = far;
         cur = near;
       } else if (h0) {
         cur = ch.x;
       } else if (h1) {
         cur = ch.y;
       } else {
-        cur = stk[sp * stride];
-        sp -= 1;
+        cur = *sp;
+        sp -= stride;
       }
     }
     if (cur == RT_REF_SENTINEL) break;
@@ -209,6 +227,7 @@ __device__ __forceinline__ void trace_ray(const SceneK& sc, const d3 o, const d3
     const uint32_t leaf = (uint32_t)~cur;
     const uint32_t first = leaf >> 2, cnt = (leaf & 3u) + 1u;
     for (uint32_t i = 0; i < cnt; ++i) {
+      if (COUNT && first_active_lane()) wc.wi_leaf++;
       const TriGeom* g = sc.geom + (first + i);
       const d3 a = mk(g->a[0], g->a[1], g->a[2]);
       const d3 a_to_b = mk(g->ab[0], g->ab[1], g->ab[2]);
@@ -238,8 +257,8 @@ __device__ __forceinline__ void trace_ray(const SceneK& sc, const d3 o, const d3
         best32k = f32_up(dist) * RT_K_FAR;
       }
     }
-    cur = stk[sp * stride];
-    sp -= 1;
+    cur = *sp;
+    sp -= stride;
   }
 
   h.t = best_t;
@@ -339,8 +358,9 @@ struct ShadeIn {
   int32_t sphere;  // sphere record index, or -1
 };
 
+template <bool COUNT>
 __device__ __forceinline__ void shade_hit(const SceneK& sc, const ShadeIn& h, const uint64_t key, const int depth, d3& o,
-                                          d3& dir, d3& thr, d3& rad) {
+                                          d3& dir, d3& thr, d3& rad, WorkCount& wc) {
   const double eps = 0.00000001;
   const d3 hit_pos = h.hit_pos;
   d3 normal;
@@ -411,6 +431,7 @@ __device__ __forceinline__ void shade_hit(const SceneK& sc, const ShadeIn& h, co
     {
       int phase = 0, inner = 0, outer = 0;
       for (;;) {
+        if (COUNT && first_active_lane()) wc.wi_reject++;
         const double x1 = rng.range(-1.0, 1.0);
         const double x2 = rng.range(-1.0, 1.0);
         inner += 1;

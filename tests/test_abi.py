@@ -33,7 +33,7 @@ def test_struct_sizes_match_header():
     assert C.sizeof(_ffi.rt_texture) == 16
     assert C.sizeof(_ffi.rt_render_params) == 64
     assert C.sizeof(_ffi.rt_scene_desc) == 112
-    assert C.sizeof(_ffi.rt_stats) == 48
+    assert C.sizeof(_ffi.rt_stats) == 80
     assert C.sizeof(_ffi.rt_timing) == 16
 
 

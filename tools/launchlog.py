@@ -37,5 +37,6 @@ for form in a.forms.split(","):
     rays = sum(l.rays for l in log)
     print(f"== {form}: wall {wall:.2f} ms, kernels {tm.ms_paths:.2f} + resolve {tm.ms_resolve:.2f} ms, {rays} rays, {rays / wall / 1e3:.0f} Mrays/s, {len(log)} launches")
     for l in log[:14]:
-        extra = f" nodes/ray {l.node_visits / max(1, l.rays):.2f} tris/ray {l.tri_tests / max(1, l.rays):.2f}" if a.count else ""
+        extra = (f" nodes/ray {l.node_visits / max(1, l.rays):.2f} tris/ray {l.tri_tests / max(1, l.rays):.2f} | per wave: inner {l.wave_iters_inner / max(1, l.waves):.1f}"
+                 f" leaf {l.wave_iters_leaf / max(1, l.waves):.1f} reject {l.wave_iters_reject / max(1, l.waves):.1f}") if a.count else ""
         print(f"   {KIND[l.kind]:8s} items {l.items:>10d} rays {l.rays:>10d} {l.ms:8.3f} ms  {l.rays / max(l.ms, 1e-6) / 1e3:8.0f} Mrays/s{extra}")

@@ -197,13 +197,25 @@ struct Rng {
   }
   // rng.gen_range(lo..hi) / gen_range(lo..=hi) — uniform on the interval.
   double range(double lo, double hi) { return lo + (hi - lo) * u01(); }
+  // The two gen_range(-1.0..1.0) calls of the Marsaglia loop (src/main.rs:266-267) from ONE
+  // draw: its high and low 32 bits, each as the top mantissa bits of a double in [1,2).
+  void pair_pm1(double* a, double* b) {
+    uint64_t z = mix64(key + GOLDEN * (stage_base + (uint64_t)index + 1));
+    index += 1;
+    uint64_t ba = 0x3ff0000000000000ull | ((z >> 32) << 20), bb = 0x3ff0000000000000ull | ((z & 0xffffffffull) << 20);
+    double da, db;
+    std::memcpy(&da, &ba, 8);
+    std::memcpy(&db, &bb, 8);
+    *a = -1.0 + 2.0 * (da - 1.0);
+    *b = -1.0 + 2.0 * (db - 1.0);
+  }
 };
 
 // src/main.rs:264-279 (Marsaglia), capped.
 Vec3 random_unit_sphere_surface(Rng& r) {
   for (int tries = 0; tries < REJECT_CAP; ++tries) {
-    double x1 = r.range(-1.0, 1.0);
-    double x2 = r.range(-1.0, 1.0);
+    double x1, x2;
+    r.pair_pm1(&x1, &x2);
     if (x1 * x1 + x2 * x2 >= 1.0) continue;
     double sq = std::sqrt(1.0 - x1 * x1 - x2 * x2);
     double x = 2.0 * x1 * sq;

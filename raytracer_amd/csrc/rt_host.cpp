@@ -546,6 +546,33 @@ int build_scene_accel(rt_scene* s) {
   s->root_ref = b.build(0, n, 0, &root_box);
   s->bvh_depth = b.max_depth;
   s->bvh_leaves = b.leaves;
+  // Renumber the interior nodes breadth-first: the first n nodes are then the top levels of
+  // the tree, the part every ray walks through and the kernels keep in LDS.
+  if (s->root_ref >= 0) {
+    const size_t nn = s->nodes.size();
+    std::vector<int32_t> order;  // new index -> old index
+    order.reserve(nn);
+    std::vector<int32_t> renum(nn, -1);
+    order.push_back(s->root_ref);
+    renum[s->root_ref] = 0;
+    for (size_t head = 0; head < order.size(); ++head) {
+      const BvhNode& nd = s->nodes[order[head]];
+      for (int c = 0; c < 2; ++c)
+        if (nd.child[c] >= 0) {
+          renum[nd.child[c]] = (int32_t)order.size();
+          order.push_back(nd.child[c]);
+        }
+    }
+    std::vector<BvhNode> sorted(nn);
+    for (size_t i = 0; i < nn; ++i) {
+      BvhNode nd = s->nodes[order[i]];
+      for (int c = 0; c < 2; ++c)
+        if (nd.child[c] >= 0) nd.child[c] = renum[nd.child[c]];
+      sorted[i] = nd;
+    }
+    s->nodes.swap(sorted);
+    s->root_ref = 0;
+  }
 
   s->tri_geom.resize(n);
   s->tri_shade.resize(n);

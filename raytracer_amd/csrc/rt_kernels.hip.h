@@ -71,14 +71,24 @@ struct Rng {
     return __longlong_as_double((long long)(0x3ff0000000000000ull | (mix64(x) >> 12))) - 1.0;
   }
   __device__ __forceinline__ double range(double lo, double hi) { return lo + (hi - lo) * u01(); }
+  // Two uniforms on [-1,1) from ONE draw: its high and low 32 bits, each as the top mantissa
+  // bits of a double in [1,2) (resolution 2^-31). Used for the Marsaglia candidate pairs.
+  __device__ __forceinline__ void pair_pm1(double& a, double& b) {
+    x += RT_GOLDEN;
+    const uint64_t z = mix64(x);
+    const double ua = __longlong_as_double((long long)(0x3ff0000000000000ull | ((z >> 32) << 20))) - 1.0;
+    const double ub = __longlong_as_double((long long)(0x3ff0000000000000ull | ((z & 0xffffffffull) << 20))) - 1.0;
+    a = -1.0 + 2.0 * ua;
+    b = -1.0 + 2.0 * ub;
+  }
   __device__ __forceinline__ void skip(uint32_t n) { x += RT_GOLDEN * (uint64_t)n; }
 };
 
 // random_unit_sphere_surface, src/main.rs:264-279 (Marsaglia), capped at RT_REJECT_CAP tries.
 __device__ __forceinline__ d3 random_unit_sphere_surface(Rng& r) {
   for (int tries = 0; tries < RT_REJECT_CAP; ++tries) {
-    double x1 = r.range(-1.0, 1.0);
-    double x2 = r.range(-1.0, 1.0);
+    double x1, x2;
+    r.pair_pm1(x1, x2);
     if (x1 * x1 + x2 * x2 >= 1.0) continue;
     double sq = sqrt(1.0 - x1 * x1 - x2 * x2);
     double x = 2.0 * x1 * sq;
@@ -110,6 +120,29 @@ struct HitK {
   int32_t sphere;  // sphere record index, or -1
 };
 
+// Diagnostic build only (-DRT_STAMPS): per-lane cycle accounting by code section. RT_ACC(wc, s)
+// charges the cycles since the previous stamp to section s. Never compiled into the library.
+#ifdef RT_STAMPS
+#define RT_NSEC 8
+__shared__ unsigned long long s_stamp[RT_BLOCK / 64][RT_NSEC + 2];  // per wave: sections, t0
+// Wave-level accounting: whichever lane is first among the active ones charges the cycles since
+// the wave's previous stamp to section s.
+#define RT_ACC(wc, s)                                                   \
+  do {                                                                  \
+    const unsigned long long m_ = __ballot(1);                          \
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) {        \
+      unsigned long long* w_ = s_stamp[threadIdx.x >> 6];               \
+      const unsigned long long now_ = clock64();                        \
+      w_[s] += now_ - w_[RT_NSEC];                                      \
+      w_[RT_NSEC] = now_;                                               \
+    }                                                                   \
+  } while (0)
+#else
+#define RT_ACC(wc, s) \
+  do {                \
+  } while (0)
+#endif
+
 struct WorkCount {
   uint32_t rays, nodes, tris, spheres, shaded;
   // loop iterations as the WAVE executes them (counted by the first active lane of each
@@ -137,16 +170,25 @@ __device__ __forceinline__ float f32_up(double x) {
   return __double2float_ru(x);
 }
 
-template <bool COUNT>
-__device__ __forceinline__ void trace_ray(const SceneK& sc, const d3 o, const d3 d, int32_t* stk, const int stride,
-                                          HitK& h, WorkCount& wc) {
-  const double eps = 0.00000001;  // src/main.rs:185
-  double best_t = __longlong_as_double(0x7ff0000000000000ll);
-  double best_u = 0.0, best_v = 0.0;
-  int32_t best_slot = -1, best_flat = 0x7fffffff;
+// Per-lane traversal state, resumable: a lane can stop after a bounded number of steps and any
+// lane of the block can pick the ray up later (the stack lives in LDS and is addressed by the
+// column index of the lane that started the ray).
+struct Trav {
+  d3 o, d;
+  float ix, iy, iz;                                 // reciprocal direction
+  float mx_lo, mx_hi, my_lo, my_hi, mz_lo, mz_hi;   // -(o -+ pad) * reciprocal direction
+  float best32k;                                    // pruning distance for the f32 box tests
+  double best_t, best_u, best_v;
+  int32_t best_slot, best_flat;
+  int32_t cur;   // next node/leaf ref, RT_REF_SENTINEL when the traversal has finished
+  int32_t* sp;   // top of the stack column (entries are `stride` ints apart)
+};
 
-  // culling ray: t = b * inv - (o -+ pad) * inv, one fused operation per plane (culling only;
-  // the fused rounding perturbs the padded origin by less than the pad already allows for)
+// Culling ray: t = b * inv - (o -+ pad) * inv, one fused operation per plane (culling only; the
+// fused rounding perturbs the padded origin by less than the pad already allows for).
+__device__ __forceinline__ void trav_set_ray(Trav& t, const d3 o, const d3 d) {
+  t.o = o;
+  t.d = d;
   const double omax = fmax(fabs(o.x), fmax(fabs(o.y), fabs(o.z)));
   const float pad = f32_up(omax * 4.76837158203125e-07);  // 2^-21
   const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
@@ -154,19 +196,55 @@ __device__ __forceinline__ void trace_ray(const SceneK& sc, const d3 o, const d3
   if (fabs(dx) < 1e-30) dx = signbit(dx) ? -1e-30 : 1e-30;
   if (fabs(dy) < 1e-30) dy = signbit(dy) ? -1e-30 : 1e-30;
   if (fabs(dz) < 1e-30) dz = signbit(dz) ? -1e-30 : 1e-30;
-  const float ix = (float)(1.0 / dx), iy = (float)(1.0 / dy), iz = (float)(1.0 / dz);
+  t.ix = (float)(1.0 / dx);
+  t.iy = (float)(1.0 / dy);
+  t.iz = (float)(1.0 / dz);
   // for a box's min plane use o + pad, for its max plane o - pad (pads the box, whatever the sign)
-  const float mx_lo = -(ox - pad) * ix, mx_hi = -(ox + pad) * ix;
-  const float my_lo = -(oy - pad) * iy, my_hi = -(oy + pad) * iy;
-  const float mz_lo = -(oz - pad) * iz, mz_hi = -(oz + pad) * iz;
-  float best32k = __int_as_float(0x7f800000);
+  t.mx_lo = -(ox - pad) * t.ix;
+  t.mx_hi = -(ox + pad) * t.ix;
+  t.my_lo = -(oy - pad) * t.iy;
+  t.my_hi = -(oy + pad) * t.iy;
+  t.mz_lo = -(oz - pad) * t.iz;
+  t.mz_hi = -(oz + pad) * t.iz;
+}
 
-  int32_t* sp = stk;  // top of this lane's stack (entries are `stride` ints apart)
-  *sp = RT_REF_SENTINEL;
-  int32_t cur = sc.root_ref;
+__device__ __forceinline__ void trav_begin(Trav& t, const SceneK& sc, const d3 o, const d3 d, int32_t* stk) {
+  trav_set_ray(t, o, d);
+  t.best32k = __int_as_float(0x7f800000);
+  t.best_t = __longlong_as_double(0x7ff0000000000000ll);
+  t.best_u = 0.0;
+  t.best_v = 0.0;
+  t.best_slot = -1;
+  t.best_flat = 0x7fffffff;
+  t.sp = stk;
+  *t.sp = RT_REF_SENTINEL;
+  t.cur = sc.root_ref;
+}
 
-  for (;;) {
+// Runs the traversal until it finishes (t.cur == RT_REF_SENTINEL) or, when BOUNDED, until the
+// lane has made `max_inner` node visits in this call.
+template <bool COUNT, bool BOUNDED>
+__device__ __forceinline__ void trav_run(Trav& t, const SceneK& sc, const int stride, WorkCount& wc, const int max_inner) {
+  const double eps = 0.00000001;  // src/main.rs:185
+  const d3 o = t.o, d = t.d;
+  const float ix = t.ix, iy = t.iy, iz = t.iz;
+  const float mx_lo = t.mx_lo, mx_hi = t.mx_hi, my_lo = t.my_lo, my_hi = t.my_hi, mz_lo = t.mz_lo, mz_hi = t.mz_hi;
+  float best32k = t.best32k;
+  double best_t = t.best_t, best_u = t.best_u, best_v = t.best_v;
+  int32_t best_slot = t.best_slot, best_flat = t.best_flat;
+  int32_t cur = t.cur;
+  int32_t* sp = t.sp;
+  int steps = 0;
+
+  while (cur != RT_REF_SENTINEL) {
+    bool paused = false;
+    RT_ACC(wc, 5);
     while (cur >= 0) {
+      if (BOUNDED && steps >= max_inner) {
+        paused = true;
+        break;
+      }
+      steps += 1;
       const float4* np = reinterpret_cast<const float4*>(sc.nodes + cur);
       const float4 bx = np[0], by = np[1], bz = np[2];
       const int4 ch = reinterpret_cast<const int4*>(np)[3];
@@ -222,7 +300,8 @@ __device__ __forceinline__ void trace_ray(const SceneK& sc, const d3 o, const d3
         sp -= stride;
       }
     }
-    if (cur == RT_REF_SENTINEL) break;
+    RT_ACC(wc, 4);
+    if (paused || cur == RT_REF_SENTINEL) break;
     // leaf
     const uint32_t leaf = (uint32_t)~cur;
     const uint32_t first = leaf >> 2, cnt = (leaf & 3u) + 1u;
@@ -260,13 +339,28 @@ __device__ __forceinline__ void trace_ray(const SceneK& sc, const d3 o, const d3
     cur = *sp;
     sp -= stride;
   }
+  RT_ACC(wc, 5);
+  t.best32k = best32k;
+  t.best_t = best_t;
+  t.best_u = best_u;
+  t.best_v = best_v;
+  t.best_slot = best_slot;
+  t.best_flat = best_flat;
+  t.cur = cur;
+  t.sp = sp;
+}
 
+// The sphere loop of Scene::hit, src/main.rs:802-810, on top of the nearest mesh hit.
+template <bool COUNT>
+__device__ __forceinline__ void finish_hit(const SceneK& sc, const d3 o, const d3 d, double best_t, double best_u,
+                                           double best_v, int32_t best_slot, HitK& h, WorkCount& wc) {
+  const double eps = 0.00000001;
   h.t = best_t;
   h.u = best_u;
   h.v = best_v;
   h.slot = best_slot;
   h.sphere = -1;
-  // src/main.rs:802-810: every sphere, in object order; strictly nearer replaces
+  // every sphere, in object order; strictly nearer replaces
   for (uint32_t i = 0; i < sc.n_spheres; ++i) {
     const SphereRec* s = sc.spheres + i;
     if (COUNT) wc.spheres++;
@@ -289,6 +383,15 @@ __device__ __forceinline__ void trace_ray(const SceneK& sc, const d3 o, const d3
       h.sphere = (int32_t)i;
     }
   }
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void trace_ray(const SceneK& sc, const d3 o, const d3 d, int32_t* stk, const int stride,
+                                          HitK& h, WorkCount& wc) {
+  Trav t;
+  trav_begin(t, sc, o, d, stk);
+  trav_run<COUNT, false>(t, sc, stride, wc, 0);
+  finish_hit<COUNT>(sc, o, d, t.best_t, t.best_u, t.best_v, t.best_slot, h, wc);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -369,12 +472,18 @@ __device__ __forceinline__ void shade_hit(const SceneK& sc, const ShadeIn& h, co
   if (h.slot >= 0) {
     const TriShade* s = sc.shade + h.slot;
     obj = s->obj;
+    const d3 n0 = mk(s->n[0][0], s->n[0][1], s->n[0][2]), n1 = mk(s->n[1][0], s->n[1][1], s->n[1][2]),
+             n2 = mk(s->n[2][0], s->n[2][1], s->n[2][2]);
+    double uv[3][2];
+    for (int k = 0; k < 3; ++k) {
+      uv[k][0] = s->uv[k][0];
+      uv[k][1] = s->uv[k][1];
+    }
     // src/main.rs:526-531 — bary_interp of the vertex normals, not normalised
     const double w = 1.0 - h.u - h.v;
-    normal = (w * mk(s->n[0][0], s->n[0][1], s->n[0][2]) + h.u * mk(s->n[1][0], s->n[1][1], s->n[1][2])) +
-             h.v * mk(s->n[2][0], s->n[2][1], s->n[2][2]);
-    tex_u = bary(s->uv[0][0], s->uv[1][0], s->uv[2][0], h.u, h.v);  // src/main.rs:485-486
-    tex_v = bary(s->uv[0][1], s->uv[1][1], s->uv[2][1], h.u, h.v);
+    normal = (w * n0 + h.u * n1) + h.v * n2;
+    tex_u = bary(uv[0][0], uv[1][0], uv[2][0], h.u, h.v);  // src/main.rs:485-486
+    tex_v = bary(uv[0][1], uv[1][1], uv[2][1], h.u, h.v);
   } else {
     const SphereRec* s = sc.spheres + h.sphere;
     obj = s->obj;
@@ -428,12 +537,13 @@ __device__ __forceinline__ void shade_hit(const SceneK& sc, const ShadeIn& h, co
     // order, one pair per iteration, so a wave pays only the longest total.
     d3 jit = mk(0.0, 0.0, 0.0);
     d3 diffuse_out = mk(0.0, 0.0, 0.0);
+    RT_ACC(wc, 0);
     {
       int phase = 0, inner = 0, outer = 0;
       for (;;) {
         if (COUNT && first_active_lane()) wc.wi_reject++;
-        const double x1 = rng.range(-1.0, 1.0);
-        const double x2 = rng.range(-1.0, 1.0);
+        double x1, x2;
+        rng.pair_pm1(x1, x2);
         inner += 1;
         const double r2 = x1 * x1 + x2 * x2;
         const bool accept = !(r2 >= 1.0);
@@ -458,6 +568,7 @@ __device__ __forceinline__ void shade_hit(const SceneK& sc, const ShadeIn& h, co
         }
       }
     }
+    RT_ACC(wc, 1);
     diffuse_out = diffuse * diffuse_out + normal;  // src/main.rs:884
     if (length(diffuse_out) < eps) {
       diffuse_out = normal;

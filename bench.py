@@ -172,7 +172,7 @@ def main():
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get(args.workload, {}).get("bytes_per_launch")
+                traffic = json.load(open(tfile)).get(args.workload, {}).get(names[dom].split(" ")[0], {}).get("bytes_per_launch")
             except Exception:
                 traffic = None
         out = {

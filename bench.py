@@ -65,14 +65,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if rt.device_count() < 1 or not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; the render path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # RT_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
+    # (ranks then share devices and the reduction goes through the host); the driver uses nccl.
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    device = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     scene_name, W, H, spp, cfg = WORKLOADS[args.workload]
     scene = scenes.build(scene_name)
-    scene.upload(local_rank)
+    scene.upload(device)
     info = scene.info()
     stream = torch.cuda.current_stream().cuda_stream
     base_flags = {"wave": 0, "mega": _ffi.RT_FLAG_MEGAKERNEL, "noregen": _ffi.RT_FLAG_NO_REGEN}[args.form]

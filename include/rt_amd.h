@@ -179,6 +179,7 @@ typedef struct rt_launch_info {
   uint64_t wave_iters_reject;
 } rt_launch_info;
 
+typedef struct rt_image rt_image;     /* a decoded texture: DynamicImage, src/main.rs:338, 389 */
 typedef struct rt_mesh rt_mesh;       /* PolygonMesh, src/main.rs:566-574 */
 typedef struct rt_objects rt_objects; /* Vec<Object> being assembled      */
 typedef struct rt_scene rt_scene;     /* Scene, src/main.rs:747           */
@@ -197,6 +198,17 @@ int rt_mesh_rotate_y(rt_mesh* mesh, double angle);
 int rt_mesh_rotate_z(rt_mesh* mesh, double angle);
 /* PolygonMesh::translate, src/main.rs:660-664 (vertices only). */
 int rt_mesh_translate(rt_mesh* mesh, const double t[3]);
+
+/* image::io::Reader::open(path).decode(), src/main.rs:1226-1232, 1273-1279, as the 8-bit RGBA
+ * pixels get_pixel returns (src/main.rs:353, 402). Non-interlaced PNG, 8 bits per sample or a
+ * palette; gamma and colour-profile chunks are ignored, as the reference's decoder ignores them. */
+int rt_image_load_png(const char* path, rt_image** out);
+void rt_image_destroy(rt_image* img);
+/* *rgba points at [height][width][4] bytes owned by the image. */
+int rt_image_info(const rt_image* img, uint32_t* width, uint32_t* height, const uint8_t** rgba);
+/* No counterpart in the reference (it draws into a window, src/main.rs:1116-1122): writes
+ * [height][width][4] 8-bit RGBA, e.g. the output of rt_quantize_rgba8, as a PNG file. */
+int rt_image_write_png(const char* path, const uint8_t* rgba, uint32_t width, uint32_t height);
 
 int rt_objects_create(rt_objects** out);
 void rt_objects_destroy(rt_objects* objs);

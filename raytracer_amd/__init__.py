@@ -6,6 +6,7 @@ scenes. Everything executes in librt_amd.so (HIP kernels + C++ host code); impor
 package fails if that library has not been built.
 """
 from . import _ffi  # noqa: F401  (loads librt_amd.so or raises)
+from ._ffi import RtError  # noqa: F401
 from .host import (  # noqa: F401
     Dielectric,
     Objects,
@@ -14,6 +15,8 @@ from .host import (  # noqa: F401
     Scene,
     device_count,
     load_obj,
+    load_png,
+    write_png,
     quantize_rgba8,
     render_params,
 )

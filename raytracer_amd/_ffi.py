@@ -153,6 +153,10 @@ SIGNATURES = {
     "rt_mesh_rotate_y": (C.c_int, [_P, C.c_double]),
     "rt_mesh_rotate_z": (C.c_int, [_P, C.c_double]),
     "rt_mesh_translate": (C.c_int, [_P, C.POINTER(C.c_double)]),
+    "rt_image_load_png": (C.c_int, [C.c_char_p, C.POINTER(_P)]),
+    "rt_image_destroy": (None, [_P]),
+    "rt_image_info": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(_P)]),
+    "rt_image_write_png": (C.c_int, [C.c_char_p, _P, C.c_uint32, C.c_uint32]),
     "rt_objects_create": (C.c_int, [C.POINTER(_P)]),
     "rt_objects_destroy": (None, [_P]),
     "rt_objects_add_texture": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32]),

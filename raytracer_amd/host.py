@@ -273,6 +273,25 @@ class Scene:
         return t
 
 
+def load_png(path):
+    """image::io::Reader::open(path).decode() as [h][w][4] uint8 (src/main.rs:1226-1232)."""
+    img = C.c_void_p()
+    check(lib.rt_image_load_png(str(path).encode(), C.byref(img)), "rt_image_load_png")
+    try:
+        w, h, px = C.c_uint32(), C.c_uint32(), C.c_void_p()
+        check(lib.rt_image_info(img, C.byref(w), C.byref(h), C.byref(px)), "rt_image_info")
+        buf = (C.c_uint8 * (w.value * h.value * 4)).from_address(px.value)
+        return np.frombuffer(buf, dtype=np.uint8).reshape(h.value, w.value, 4).copy()
+    finally:
+        lib.rt_image_destroy(img)
+
+
+def write_png(path, rgba):
+    a = np.ascontiguousarray(rgba, dtype=np.uint8)
+    assert a.ndim == 3 and a.shape[2] == 4
+    check(lib.rt_image_write_png(str(path).encode(), _ptr(a), a.shape[1], a.shape[0]), "rt_image_write_png")
+
+
 def quantize_rgba8(canvas, its):
     """The display loop's canvas update, src/main.rs:1106-1112 with 29-37."""
     h, w, _ = canvas.shape

@@ -8,20 +8,17 @@ spot_grid_scene: floor plus nx x nz duplicated cows (the reference has no instan
 """
 import os
 
-import numpy as np
-
 from .host import Dielectric, Objects, Opaque, Scene, deg, load_obj
 
 ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets")
 
 
 def load_texture(path):
-    """Decodes a PNG to [h][w][4] uint8, ignoring gamma/colour-profile chunks as the reference's
-    decoder does (src/main.rs:1226-1232 via image 0.23)."""
-    from PIL import Image
+    """Decodes a PNG to [h][w][4] uint8 with the library's own decoder, which ignores
+    gamma/colour-profile chunks as the reference's does (src/main.rs:1226-1232 via image 0.23)."""
+    from .host import load_png
 
-    with Image.open(path) as im:
-        return np.ascontiguousarray(np.asarray(im.convert("RGBA"), dtype=np.uint8))
+    return load_png(path)
 
 
 def _floor(objects, assets):

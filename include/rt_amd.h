@@ -219,6 +219,22 @@ int rt_objects_push_mesh(rt_objects* objs, const rt_mesh* mesh, const rt_materia
 /* Object::sphere, src/main.rs:454-461. Returns the object index or a negative error. */
 int rt_objects_push_sphere(rt_objects* objs, const double centre[3], double radius, const rt_material* mat);
 
+/* Scene description file: the calls sphere_scene() / lens_scene() make (src/main.rs:1270-1450,
+ * 1223-1268) read from text instead of being compiled in (src/main.rs:1077-1078). One statement
+ * per line, '#' comments, paths relative to the file:
+ *   texture NAME FILE.png
+ *   mesh FILE.obj [rotate_x DEG | rotate_y DEG | rotate_z DEG | translate X Y Z]... MATERIAL
+ *   sphere X Y Z RADIUS MATERIAL
+ *   render [width W] [height H] [spp S] [its N] [seed K] [max_depth D] [fov F] [dof X]
+ *   MATERIAL = opaque [color R G B | color texture NAME] [normal NAME] [metallic M]
+ *              [how_metallic H] [diffuse D] [emission R G B]  |  dielectric IOR
+ * Angles become DEG * PI / 180.0 as at src/main.rs:1340. params (may be NULL) receives the
+ * reference's constants overridden by the file's render statement; its (may be NULL) the number
+ * of render calls to accumulate (the reference's display loop has no end; default 1). */
+int rt_scene_file_load(const char* path, rt_objects** out, rt_render_params* params, uint32_t* its);
+/* The constants of src/main.rs:1041-1052 and 978: 1600x1200, 10 spp, depth 200, fov 60, dof 0. */
+void rt_render_params_default(rt_render_params* p);
+
 /* Scene::from_objects, src/main.rs:750-774: flattens meshes in object order and builds the
  * acceleration structure (replaces BVH::build of crate bvh 0.6.0, src/main.rs:771). */
 int rt_scene_from_objects(const rt_objects* objs, rt_scene** out);
@@ -229,6 +245,12 @@ int rt_scene_get_info(const rt_scene* scene, rt_scene_info* out);
 /* Copies the flat triangle arrays out (any pointer may be NULL). Layouts as in rt_scene_desc. */
 int rt_scene_export_flat(const rt_scene* scene, double* tri_vertices, double* tri_normals,
                          double* tri_uvs, int32_t* tri_obj, int32_t* tri_idx);
+/* Copies the object list out: kinds and materials are [n_objects], spheres [n_spheres][4]
+ * (centre, radius) with their object indices (any pointer may be NULL). */
+int rt_scene_export_objects(const rt_scene* scene, int32_t* object_kind, rt_material* materials,
+                            double* spheres, int32_t* sphere_obj);
+/* Size of texture `id`, and its [height][width][4] bytes if rgba is not NULL. */
+int rt_scene_export_texture(const rt_scene* scene, uint32_t id, uint32_t* width, uint32_t* height, uint8_t* rgba);
 /* Copies the acceleration structure out: nodes as bvh_nodes x 16 32-bit words (layout in
  * raytracer_amd/csrc/rt_types.h), and for each triangle slot in leaf order its flat index. */
 int rt_scene_export_bvh(const rt_scene* scene, uint32_t* node_words, int32_t* leaf_order);

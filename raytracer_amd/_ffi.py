@@ -162,11 +162,15 @@ SIGNATURES = {
     "rt_objects_add_texture": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32]),
     "rt_objects_push_mesh": (C.c_int, [_P, _P, C.POINTER(rt_material)]),
     "rt_objects_push_sphere": (C.c_int, [_P, C.POINTER(C.c_double), C.c_double, C.POINTER(rt_material)]),
+    "rt_scene_file_load": (C.c_int, [C.c_char_p, C.POINTER(_P), _P, C.POINTER(C.c_uint32)]),
+    "rt_render_params_default": (None, [_P]),
     "rt_scene_from_objects": (C.c_int, [_P, C.POINTER(_P)]),
     "rt_scene_create": (C.c_int, [C.POINTER(rt_scene_desc), C.POINTER(_P)]),
     "rt_scene_destroy": (None, [_P]),
     "rt_scene_get_info": (C.c_int, [_P, C.POINTER(rt_scene_info)]),
     "rt_scene_export_flat": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "rt_scene_export_objects": (C.c_int, [_P, _P, _P, _P, _P]),
+    "rt_scene_export_texture": (C.c_int, [_P, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _P]),
     "rt_scene_export_bvh": (C.c_int, [_P, _P, _P]),
     "rt_device_count": (C.c_int, []),
     "rt_scene_upload": (C.c_int, [_P, C.c_int]),

@@ -816,6 +816,40 @@ extern "C" int rt_scene_export_bvh(const rt_scene* s, uint32_t* node_words, int3
   return RT_OK;
 }
 
+extern "C" int rt_scene_export_objects(const rt_scene* s, int32_t* object_kind, rt_material* materials, double* spheres,
+                                       int32_t* sphere_obj) {
+  if (!s) {
+    rt_set_error("rt_scene_export_objects: null scene");
+    return RT_ERR_INVALID;
+  }
+  const size_t n = s->object_kind.size();
+  if (object_kind && n) std::memcpy(object_kind, s->object_kind.data(), n * sizeof(int32_t));
+  if (materials && n) std::memcpy(materials, s->materials.data(), n * sizeof(rt_material));
+  for (size_t i = 0; i < s->spheres.size(); ++i) {
+    const SphereRec& r = s->spheres[i];
+    if (spheres) {
+      spheres[i * 4 + 0] = r.c[0];
+      spheres[i * 4 + 1] = r.c[1];
+      spheres[i * 4 + 2] = r.c[2];
+      spheres[i * 4 + 3] = r.r;
+    }
+    if (sphere_obj) sphere_obj[i] = r.obj;
+  }
+  return RT_OK;
+}
+
+extern "C" int rt_scene_export_texture(const rt_scene* s, uint32_t id, uint32_t* width, uint32_t* height, uint8_t* rgba) {
+  if (!s || id >= s->textures.size()) {
+    rt_set_error("rt_scene_export_texture: null scene or texture id out of range");
+    return RT_ERR_INVALID;
+  }
+  const HostTexture& t = s->textures[id];
+  if (width) *width = t.w;
+  if (height) *height = t.h;
+  if (rgba) std::memcpy(rgba, t.rgba.data(), t.rgba.size());
+  return RT_OK;
+}
+
 // impl Into<Rgba<u8>> for RGBA, src/main.rs:29-37, on canvas / its (src/main.rs:1109).
 extern "C" int rt_quantize_rgba8(const double* canvas, uint32_t w, uint32_t h, uint32_t its, uint8_t* out) {
   if (!canvas || !out || its == 0) {

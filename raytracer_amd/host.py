@@ -110,6 +110,15 @@ class Objects:
         if h:
             lib.rt_objects_destroy(h)
 
+    @staticmethod
+    def from_file(path):
+        """Replays a scene description file; returns (objects, render params, its)."""
+        out, p, its = C.c_void_p(), _ffi.rt_render_params(), C.c_uint32()
+        check(lib.rt_scene_file_load(str(path).encode(), C.byref(out), C.byref(p), C.byref(its)), "rt_scene_file_load")
+        objs = Objects.__new__(Objects)
+        objs._h = out
+        return objs, p, its.value
+
     def add_texture(self, rgba):
         a = np.ascontiguousarray(rgba, dtype=np.uint8)
         assert a.ndim == 3 and a.shape[2] == 4, "texture must be [h][w][4] uint8"
@@ -156,6 +165,12 @@ class Scene:
         out = C.c_void_p()
         check(lib.rt_scene_from_objects(objs._h, C.byref(out)), "rt_scene_from_objects")
         return Scene(out.value)
+
+    @staticmethod
+    def from_file(path):
+        """Scene of a description file; returns (scene, render params, its)."""
+        objs, p, its = Objects.from_file(path)
+        return Scene.from_objects(objs), p, its
 
     @staticmethod
     def from_desc(object_kind, materials, tri_vertices, tri_normals, tri_uvs, tri_obj, tri_idx, spheres, sphere_obj,
@@ -211,6 +226,23 @@ class Scene:
         tobj = np.empty(n, np.int32); tidx = np.empty(n, np.int32)
         check(lib.rt_scene_export_flat(self._h, _ptr(tv), _ptr(tn), _ptr(tuv), _ptr(tobj), _ptr(tidx)), "rt_scene_export_flat")
         return tv, tn, tuv, tobj, tidx
+
+    def export_objects(self):
+        """(object kinds, materials as a ctypes array, spheres [n][4], sphere object indices)."""
+        i = self.info()
+        kind = np.zeros(i.n_objects, np.int32)
+        mats = (_ffi.rt_material * i.n_objects)()
+        sph = np.zeros((i.n_spheres, 4)); sobj = np.zeros(i.n_spheres, np.int32)
+        check(lib.rt_scene_export_objects(self._h, _ptr(kind), C.cast(mats, C.c_void_p), _ptr(sph), _ptr(sobj)),
+              "rt_scene_export_objects")
+        return kind, mats, sph, sobj
+
+    def export_texture(self, tex_id):
+        w, h = C.c_uint32(), C.c_uint32()
+        check(lib.rt_scene_export_texture(self._h, tex_id, C.byref(w), C.byref(h), None), "rt_scene_export_texture")
+        px = np.zeros((h.value, w.value, 4), np.uint8)
+        check(lib.rt_scene_export_texture(self._h, tex_id, None, None, _ptr(px)), "rt_scene_export_texture")
+        return px
 
     def export_bvh(self):
         i = self.info()

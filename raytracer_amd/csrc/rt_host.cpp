@@ -5,15 +5,18 @@
 // the reference's binary64 arithmetic produces.
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <limits>
 #include <memory>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rt_types.h"
@@ -372,14 +375,24 @@ const double COST_NODE = 1.0;  // one 64-byte fetch + two f32 slab tests
 const double COST_TRI = 2.0;   // one 80-byte fetch + binary64 Moller-Trumbore
 const int N_BINS = 16;
 
+// What one subtree build produces besides its root ref: its interior nodes with refs local to
+// this vector, and the two tree statistics.
+struct Subtree {
+  std::vector<BvhNode> nodes;
+  uint32_t max_depth = 0;
+  uint32_t leaves = 0;
+};
+
+// Large subtrees are built on their own threads (the index ranges are disjoint). The tree does
+// not depend on how many threads ran: nodes are renumbered breadth-first afterwards.
+const size_t PARALLEL_MIN_TRIS = 16384;
+
 struct Builder {
   const std::vector<Box>& tb;      // per flat triangle
   const std::vector<double>& cen;  // centroids, 3 per triangle
   std::vector<int32_t>& idx;       // permutation being built = leaf order
-  std::vector<BvhNode>& nodes;
+  std::vector<int32_t>& scratch;   // same size as idx
   double pad;
-  uint32_t max_depth = 0;
-  uint32_t leaves = 0;
 
   static int levels_needed(size_t n) {  // interior levels a balanced split of n triangles needs
     int l = 0;
@@ -401,8 +414,22 @@ struct Builder {
     n.child[c] = ref;
   }
 
-  // Builds [lo,hi) and returns its ref; depth = interior nodes above this subtree.
-  int32_t build(size_t lo, size_t hi, uint32_t depth, Box* out_box) {
+  // Appends `sub` to `into`, shifting its local node refs; returns the shifted root ref.
+  static int32_t splice(Subtree& into, Subtree& sub, int32_t ref) {
+    const int32_t off = (int32_t)into.nodes.size();
+    for (BvhNode nd : sub.nodes) {
+      for (int c = 0; c < 2; ++c)
+        if (nd.child[c] >= 0) nd.child[c] += off;
+      into.nodes.push_back(nd);
+    }
+    into.max_depth = std::max(into.max_depth, sub.max_depth);
+    into.leaves += sub.leaves;
+    return ref >= 0 ? ref + off : ref;
+  }
+
+  // Builds [lo,hi) into `out` and returns its ref; depth = interior nodes above this subtree;
+  // fork_levels = how many more levels may hand their left child to a new thread.
+  int32_t build(size_t lo, size_t hi, uint32_t depth, Box* out_box, Subtree& out, int fork_levels) {
     const size_t n = hi - lo;
     Box bounds = box_empty(), cb = box_empty();
     for (size_t i = lo; i < hi; ++i) {
@@ -468,12 +495,20 @@ struct Builder {
         const double split_cost = COST_NODE + (area > 0.0 ? best_cost / area : (double)n) * COST_TRI;
         if (n > RT_LEAF_MAX || split_cost < (double)n * COST_TRI) {
           const double c0 = cb.lo[best_axis], scale = (double)N_BINS / (cb.hi[best_axis] - cb.lo[best_axis]);
-          auto it = std::stable_partition(idx.begin() + lo, idx.begin() + hi, [&](int32_t t) {
+          // stable partition through the builder's scratch array (ranges of concurrent subtree
+          // builds are disjoint, so they share it without locking)
+          size_t nl = lo, nr = lo;
+          for (size_t i = lo; i < hi; ++i) {
+            const int32_t t = idx[i];
             int b = (int)((cen[(size_t)t * 3 + best_axis] - c0) * scale);
             b = std::min(std::max(b, 0), N_BINS - 1);
-            return b <= best_bin;
-          });
-          mid = (size_t)(it - idx.begin());
+            if (b <= best_bin)
+              idx[nl++] = t;
+            else
+              scratch[nr++] = t;
+          }
+          std::copy(scratch.begin() + lo, scratch.begin() + nr, idx.begin() + nl);
+          mid = nl;
           split = mid > lo && mid < hi;
         }
       }
@@ -492,18 +527,28 @@ struct Builder {
     }
     if (!split) {
       std::sort(idx.begin() + lo, idx.begin() + hi);  // flat order inside a leaf
-      leaves++;
-      max_depth = std::max(max_depth, depth);
+      out.leaves++;
+      out.max_depth = std::max(out.max_depth, depth);
       return ~(int32_t)(lo * 4 + (n - 1));
     }
-    const int32_t me = (int32_t)nodes.size();
-    nodes.emplace_back();
-    std::memset(&nodes[me], 0, sizeof(BvhNode));
+    const int32_t me = (int32_t)out.nodes.size();
+    out.nodes.emplace_back();
+    std::memset(&out.nodes[me], 0, sizeof(BvhNode));
     Box lb, rb;
-    int32_t l = build(lo, mid, depth + 1, &lb);
-    int32_t r = build(mid, hi, depth + 1, &rb);
-    store_child(nodes[me], 0, lb, l);
-    store_child(nodes[me], 1, rb, r);
+    int32_t l, r;
+    if (fork_levels > 0 && n >= PARALLEL_MIN_TRIS) {
+      Subtree left, right;
+      std::future<int32_t> fl = std::async(std::launch::async, [&] { return build(lo, mid, depth + 1, &lb, left, fork_levels - 1); });
+      r = build(mid, hi, depth + 1, &rb, right, fork_levels - 1);
+      l = fl.get();
+      l = splice(out, left, l);
+      r = splice(out, right, r);
+    } else {
+      l = build(lo, mid, depth + 1, &lb, out, 0);
+      r = build(mid, hi, depth + 1, &rb, out, 0);
+    }
+    store_child(out.nodes[me], 0, lb, l);
+    store_child(out.nodes[me], 1, rb, r);
     return me;
   }
 };
@@ -519,6 +564,14 @@ int build_scene_accel(rt_scene* s) {
   s->bvh_leaves = 0;
   if (n == 0) return RT_OK;
 
+  // RT_BUILD_TIMING=1 prints the elapsed time after each phase of the build to stderr.
+  const auto t_start = std::chrono::steady_clock::now();
+  const bool timing = std::getenv("RT_BUILD_TIMING") != nullptr;
+  auto lap = [&](const char* phase) {
+    if (timing)
+      std::fprintf(stderr, "[rt build] %-9s %.3f s\n", phase,
+                   std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
+  };
   std::vector<Box> tb(n);
   std::vector<double> cen(n * 3);
   double extent = 1.0;
@@ -540,12 +593,23 @@ int build_scene_accel(rt_scene* s) {
   // covers the rounding slop of the binary64 triangle test (a hit accepted a hair outside
   // the exact triangle) with five orders of magnitude to spare for well-conditioned hits.
   const double pad = extent * 9.5367431640625e-07;
-  Builder b{tb, cen, s->leaf_order, s->nodes, pad};
-  s->nodes.reserve(n);
+  std::vector<int32_t> scratch(n);
+  Builder b{tb, cen, s->leaf_order, scratch, pad};
+  int fork_levels = 0;  // 2^fork_levels subtree builds run at once; RT_BUILD_THREADS caps it
+  {
+    unsigned threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char* e = std::getenv("RT_BUILD_THREADS")) threads = (unsigned)std::max(1, std::atoi(e));
+    while ((2u << fork_levels) <= threads && fork_levels < 6) ++fork_levels;
+  }
+  lap("boxes");
+  Subtree whole;
+  whole.nodes.reserve(n < PARALLEL_MIN_TRIS ? n : 0);
   Box root_box;
-  s->root_ref = b.build(0, n, 0, &root_box);
-  s->bvh_depth = b.max_depth;
-  s->bvh_leaves = b.leaves;
+  s->root_ref = b.build(0, n, 0, &root_box, whole, fork_levels);
+  lap("tree");
+  s->nodes.swap(whole.nodes);
+  s->bvh_depth = whole.max_depth;
+  s->bvh_leaves = whole.leaves;
   // Renumber the interior nodes breadth-first: the first n nodes are then the top levels of
   // the tree, the part every ray walks through and the kernels keep in LDS.
   if (s->root_ref >= 0) {
@@ -574,6 +638,7 @@ int build_scene_accel(rt_scene* s) {
     s->root_ref = 0;
   }
 
+  lap("renumber");
   s->tri_geom.resize(n);
   s->tri_shade.resize(n);
   for (size_t slot = 0; slot < n; ++slot) {
@@ -595,6 +660,7 @@ int build_scene_accel(rt_scene* s) {
     sh.tri = s->tri_idx[t];
     sh.obj = s->tri_obj[t];
   }
+  lap("records");
   return RT_OK;
 }
 

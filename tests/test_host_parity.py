@@ -201,3 +201,15 @@ def test_device_calls_fail_loudly_without_gpu():
     with pytest.raises(_ffi.RtError):
         s.render(canvas, rt.render_params(width=8, height=8, spp=1))
     assert not canvas.any()
+
+
+def test_tree_does_not_depend_on_builder_threads(monkeypatch):
+    """Large subtrees are built on separate threads; the tree must be the same for any count."""
+    trees = []
+    for threads in ("1", "3", "16"):
+        monkeypatch.setenv("RT_BUILD_THREADS", threads)
+        s = scenes.build("ogre")  # 39857 triangles: forks at the top two levels
+        trees.append(s.export_bvh() + (s.info().bvh_depth, s.info().bvh_leaves))
+    for nodes, order, depth, leaves in trees[1:]:
+        assert np.array_equal(nodes, trees[0][0]) and np.array_equal(order, trees[0][1])
+        assert (depth, leaves) == trees[0][2:]

@@ -155,7 +155,7 @@ def main():
         # bytes per ray = 64 B per interior node visited + 192 B per triangle tested (72 B
         # vertices + 72 B vertex normals + 48 B texture coordinates) + 48 B ray in + 40 B hit out,
         # with that kernel's own per-ray means from the counting build.
-        names = {0: "k_wave<false,0> (camera + trace)", 1: "k_wave<false,1> (shade + trace, ray queue)",
+        names = {0: "k_wave<false,0> (camera + trace + first bounce)", 1: "k_wave<false,1> (shade + trace, hit queue)",
                  2: "k_wave<false,2> (tail loop)", 3: "k_paths (single-kernel form)", 4: "k_resolve"}
         dom = max((k for k in timed if k != 4), key=lambda k: timed[k][0])
         d_ms, d_launches, d_rays = timed[dom]
@@ -221,12 +221,15 @@ def main():
                 "rays_per_launch": int(rays_per_launch),
                 "launches_per_frame": round(d_launches / args.steps, 2),
                 "resolve_ms": round(float(np.mean(ms_resolve)), 4),
+                "note": "achieved counts the algorithmic bytes of every node visit and triangle test; this scene's tree and triangles "
+                        "stay in cache, so a fraction above what HBM could deliver means the kernel is not HBM bound (traffic = measured "
+                        "HBM bytes per launch); its VALU issue rate is what limits it",
                 "valu": {
                     "achieved_tflops": round(flops_per_ray * rays_per_launch / (launch_ms * 1e-3) / 1e12, 4),
                     "flops_per_ray": round(flops_per_ray, 1),
                     "peak_fp64_tflops": FP64_PEAK_TFLOPS,
                     "peak_fp32_tflops": FP32_PEAK_TFLOPS,
-                    "note": "traversal slab tests are f32, triangle/sphere tests f64; working set fits L2, so the kernel is VALU/latency bound, not HBM bound",
+                    "note": "traversal slab tests are f32, triangle/sphere tests f64",
                 },
             },
         }

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Profiles bench.py's default workload on the GPU box. Usage (through gpurun, from the repo root):
-#   bash profiles/run_profile.sh <tag>
+#   bash profiles/run_profile.sh <tag>          (BENCH_ARGS="--workload ..." adds bench.py options)
+# then, anywhere:  python tools/pmc_summary.py gpurun_out/prof_<tag> profiles/<round>/<tag>
 # Writes rocprofv3 output under gpurun_out/prof_<tag>/; copy the summaries into profiles/.
 set -e
 TAG=${1:-r01}
@@ -8,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="$R/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+ARGS="$R/bench.py --steps 5 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-}"
 timeout -s KILL 120 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/pmc_fetch.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS > $OUT/pmc_write.log 2>&1

@@ -42,7 +42,7 @@ using namespace rtk;
 #define RT_LINE_WORDS 16   /* 64-bit words per line (128 B)                             */
 #define RT_WORK_BATCH 1024 /* path indices a wave takes from the work counter at a time */
 // words of a line
-enum { CNT_RAYS = 0, CNT_NODES, CNT_TRIS, CNT_SPHERES, CNT_SHADED, CNT_PATHS, CNT_Q0, CNT_Q1, CNT_WORK, CNT_WI_INNER, CNT_WI_LEAF, CNT_WI_REJECT, CNT_WAVES, CNT_N };
+enum { CNT_RAYS = 0, CNT_NODES, CNT_TRIS, CNT_SPHERES, CNT_SHADED, CNT_PATHS, CNT_Q0, CNT_R0, CNT_Q1, CNT_R1, CNT_WORK, CNT_WI_INNER, CNT_WI_LEAF, CNT_WI_REJECT, CNT_WAVES, CNT_N };
 #define RT_COUNTER_BYTES ((size_t)RT_SHARDS * RT_LINE_WORDS * sizeof(unsigned long long))
 
 struct DeviceScene {
@@ -366,6 +366,8 @@ struct PathParams {
   uint32_t spp;           // samples in this launch
   uint32_t first_sample;  // stream index of this launch's sample 0
   int32_t max_depth;
+  uint32_t fuse_bounces;  // bounces the first wavefront stage follows before it queues its hits
+  uint32_t short_steps;   // node visits a scattered ray gets before it is queued as a long ray
 };
 
 // Path index -> pixel and sample; starts the path (camera ray, src/main.rs:995-1013).
@@ -494,27 +496,40 @@ __global__ __launch_bounds__(RT_BLOCK) void k_paths(SceneK sc, PathParams pp, do
 }
 
 // ------------------------------------------------------------------------------------------
-// Wavefront form of the same loop: one launch per bounce over a compacted queue of the paths
-// that are still alive. Stage 0 starts every path of the launch (camera ray) and traces it;
-// stage 1 takes a queue of hits, shades each (all lanes have a hit, so the scatter code runs on
-// full waves), traces the scattered ray, and appends the survivors to the next queue with one
-// atomic per wave; stage 2 is stage 1 that keeps looping until its paths end, for the thin tail
-// of long paths. A path that misses adds throughput * sky and writes its sample; nothing else
-// is ever written twice, so results do not depend on queue order.
+// Wavefront form of the same loop: launches over compacted queues of the paths still alive.
 //
-// A queue is n_seg segments of seg_cap records; segment s has its tail in counter line s.
-// Stage 0 block b appends to segment b % n_seg; later stages run on a (n_seg, blocks) grid whose
-// blockIdx.x is the segment they read AND append to, so a segment never outgrows its first
-// filling and concurrently running blocks spread over all tails.
+// What costs a wave most is one lane walking deep into the tree while the other 63 wait: most
+// scattered rays leave the scene within a few node visits, a minority needs dozens. So a
+// scattered ray is first traced for at most `short_steps` node visits. If that settles it, the
+// lane goes on as before (miss: add throughput * sky, write the sample; hit: queue the hit).
+// If not, the ray itself is queued, and a later launch traces the long rays together, in waves
+// that are all long. Two kinds of queue record, one buffer:
+//   hit record  (a hit waiting to be shaded)  appended at the front of a segment,
+//   ray record  (a ray waiting to be traced)  appended at the back of the same segment.
+//
+// Stage 0 starts every path (camera ray) and traces it to the end — primary rays of one 8x8
+// tile walk the same nodes — then shades and short-traces the first `fuse_bounces` bounces
+// itself: a wave's primary rays hit one surface or all miss, so compacting them first would buy
+// nothing and cost a queue record per hit. Stage 1 runs over a queue: blocks of hit records
+// shade and short-trace, blocks of ray records trace to the end; both append to the other
+// queue. Stage 2 is stage 1 that keeps every path until it ends, for the thin tail of long
+// paths. Every path writes its sample exactly once, into its own slot, so results do not
+// depend on queue order.
+//
+// A queue is n_seg segments of seg_cap records; segment s keeps its two counts in counter line
+// s. Stage 0 block b appends to segment b % n_seg; later stages run on a (n_seg, blocks) grid
+// whose blockIdx.x is the segment they read AND append to, so a segment never outgrows its
+// first filling (an input record yields at most one output record) and concurrently running
+// blocks spread over all counter lines.
 // ------------------------------------------------------------------------------------------
 struct alignas(16) QueueRec {  // 112 B
-  double hit_pos[3];
-  double dir[3];
+  double hit_pos[3];  // hit record: the hit point; ray record: the ray origin
+  double dir[3];      // hit record: the direction the path arrived along; ray record: the ray
   double thr[3];
-  double u, v;
+  double u, v;        // hit record only
   uint64_t key;
   uint32_t path;
-  int32_t id;  // >= 0: triangle slot; < 0: ~sphere index
+  int32_t id;  // hit record only: >= 0 triangle slot, < 0 ~sphere index
   int32_t depth;
   int32_t pad;
 };
@@ -524,35 +539,57 @@ struct QueueView {
   QueueRec* recs;
   double* rad;        // [entries][3], only when the scene has emitters
   uint32_t seg_cap;   // records per segment
-  uint32_t tail_word; // CNT_Q0 or CNT_Q1: which word of a counter line holds this queue's tails
+  uint32_t hit_word;  // word of a counter line: hit records at the front of the segment
+  uint32_t ray_word;  // word of a counter line: ray records at the back of the segment
 };
+
+// One atomic per wave: reserves room for the lanes of `mask` in a segment count; returns the
+// calling lane's index within the segment's front (or back) run.
+__device__ __forceinline__ uint32_t wave_reserve(unsigned long long* word, unsigned long long mask, int lane) {
+  const int leader = __ffsll((long long)mask) - 1;
+  unsigned int base = 0;
+  if (lane == leader) base = atomicAdd(reinterpret_cast<unsigned int*>(word), (unsigned int)__popcll(mask));
+  base = __shfl(base, leader);
+  return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
 
 template <bool COUNT, int STAGE>
 __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, QueueView in, QueueView out, uint32_t n_seg,
-                                                   double* __restrict__ samples, unsigned long long* counters) {
+                                                   uint32_t hit_blocks, double* __restrict__ samples, unsigned long long* counters) {
   int32_t* stk = g_stack + threadIdx.x;
   const int stride = blockDim.x;
   const int lane = threadIdx.x & 63;
+  const int unbounded = 0x7fffffff;
   WorkCount wc{};
   uint32_t n_done = 0;
-  uint32_t seg, n_in;
+  uint32_t seg;
   size_t entry = 0;
   bool alive;
+  bool ray_block = false;  // this block reads ray records (uniform over the block)
   if (STAGE == 0) {
     seg = blockIdx.x % n_seg;
-    n_in = pp.n_paths;
-    alive = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x < n_in;
+    alive = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x < pp.n_paths;
   } else {
     seg = blockIdx.x;
-    n_in = (uint32_t)counters[(size_t)seg * RT_LINE_WORDS + in.tail_word];
-    const uint32_t i = blockIdx.y * RT_BLOCK + threadIdx.x;
-    alive = i < n_in;
-    entry = (size_t)seg * in.seg_cap + i;
+    const unsigned long long* line = counters + (size_t)seg * RT_LINE_WORDS;
+    ray_block = blockIdx.y >= hit_blocks;
+    if (!ray_block) {
+      const uint32_t i = blockIdx.y * RT_BLOCK + threadIdx.x;
+      alive = i < (uint32_t)line[in.hit_word];
+      entry = (size_t)seg * in.seg_cap + i;
+    } else {
+      const uint32_t i = (blockIdx.y - hit_blocks) * RT_BLOCK + threadIdx.x;
+      alive = i < (uint32_t)line[in.ray_word];
+      entry = (size_t)seg * in.seg_cap + (in.seg_cap - 1u - (alive ? i : 0u));
+    }
   }
   uint32_t path = 0;
   uint64_t key = 0;
   int depth = 0;
   d3 o = mk(0, 0, 0), dir = mk(0, 0, 0), thr = mk(1, 1, 1), rad = mk(0, 0, 0);
+  uint32_t fuse_left = STAGE == 0 ? pp.fuse_bounces : 0u;
+  // node visits the next trace may make before its ray is queued instead
+  int budget = (STAGE == 1 && !ray_block) ? (int)pp.short_steps : unbounded;
 
   if (alive) {
     if (STAGE == 0) {
@@ -561,49 +598,67 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
       if (!alive) store_sample(samples, pp.n_paths, path, mk(0.0, 0.0, 0.0));
     } else {
       const QueueRec* r = in.recs + entry;
-      ShadeIn si;
-      si.hit_pos = mk(r->hit_pos[0], r->hit_pos[1], r->hit_pos[2]);
+      const d3 p0 = mk(r->hit_pos[0], r->hit_pos[1], r->hit_pos[2]);
       dir = mk(r->dir[0], r->dir[1], r->dir[2]);
       thr = mk(r->thr[0], r->thr[1], r->thr[2]);
-      si.u = r->u;
-      si.v = r->v;
       key = r->key;
       path = r->path;
-      const int32_t id = r->id;
       depth = r->depth;
-      si.slot = id >= 0 ? id : -1;
-      si.sphere = id >= 0 ? -1 : ~id;
       if (sc.has_emission) rad = mk(in.rad[entry * 3], in.rad[entry * 3 + 1], in.rad[entry * 3 + 2]);
-      if (COUNT) wc.shaded++;
-      shade_hit<COUNT>(sc, si, key, depth, o, dir, thr, rad, wc);
-      depth += 1;
-      if (depth > pp.max_depth) {  // src/main.rs:818
-        store_sample(samples, pp.n_paths, path, rad);
-        alive = false;
-        n_done++;
+      if (ray_block) {
+        o = p0;
+      } else {
+        ShadeIn si;
+        si.hit_pos = p0;
+        si.u = r->u;
+        si.v = r->v;
+        const int32_t id = r->id;
+        si.slot = id >= 0 ? id : -1;
+        si.sphere = id >= 0 ? -1 : ~id;
+        if (COUNT) wc.shaded++;
+        shade_hit<COUNT>(sc, si, key, depth, o, dir, thr, rad, wc);
+        depth += 1;
+        if (depth > pp.max_depth) {  // src/main.rs:818
+          store_sample(samples, pp.n_paths, path, rad);
+          alive = false;
+          n_done++;
+        }
       }
     }
   }
 
+  HitK h;
+  h.slot = -1;
+  h.sphere = -1;
+  bool deferred = false;  // this lane's ray ran out of budget: queue the ray
   for (;;) {
-    HitK h;
-    h.slot = -1;
-    h.sphere = -1;
-    bool hit = false;
     if (alive) {
-      wc.rays++;
-      trace_ray<COUNT>(sc, o, dir, stk, stride, h, wc);
-      hit = h.slot >= 0 || h.sphere >= 0;
-      if (!hit) {
-        const d3 s = sky(dir);  // src/main.rs:826
-        rad = rad + mk(thr.x * s.x, thr.y * s.y, thr.z * s.z);
-        store_sample(samples, pp.n_paths, path, rad);
+      Trav t;
+      trav_begin(t, sc, o, dir, stk);
+      if (budget == unbounded) trav_run<COUNT, false>(t, sc, stride, wc, 0);
+      else trav_run<COUNT, true>(t, sc, stride, wc, budget);
+      if (t.cur != RT_REF_SENTINEL) {
+        deferred = true;
         alive = false;
-        n_done++;
+      } else {
+        wc.rays++;  // a nearest-hit query is counted where it completes
+        finish_hit<COUNT>(sc, o, dir, t.best_t, t.best_u, t.best_v, t.best_slot, h, wc);
+        if (!(h.slot >= 0 || h.sphere >= 0)) {
+          const d3 s = sky(dir);  // src/main.rs:826
+          rad = rad + mk(thr.x * s.x, thr.y * s.y, thr.z * s.z);
+          store_sample(samples, pp.n_paths, path, rad);
+          alive = false;
+          n_done++;
+        }
       }
     }
-    if (STAGE == 2) {
+    // from here on `alive` means: has a hit waiting to be shaded
+    if (STAGE == 2 || (STAGE == 0 && fuse_left > 0)) {
       if (!__any(alive)) break;
+      if (STAGE == 0) {
+        fuse_left--;
+        budget = (int)pp.short_steps;
+      }
       if (alive) {
         if (COUNT) wc.shaded++;
         const ShadeIn si = shade_input(h, o, dir);
@@ -617,42 +672,47 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
       }
       continue;
     }
-    // append the survivors to this block's segment: one atomic per wave
-    const unsigned long long mask = __ballot(hit);
-    if (mask) {
-      const int leader = __ffsll((long long)mask) - 1;
-      unsigned int base = 0;
-      if (lane == leader)
-        base = atomicAdd(reinterpret_cast<unsigned int*>(&counters[(size_t)seg * RT_LINE_WORDS + out.tail_word]), (unsigned int)__popcll(mask));
-      base = __shfl(base, leader);
-      if (hit) {
-        const size_t e = (size_t)seg * out.seg_cap + base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        QueueRec* r = out.recs + e;
-        const d3 hp = o + h.t * dir;  // src/main.rs:831
-        r->hit_pos[0] = hp.x;
-        r->hit_pos[1] = hp.y;
-        r->hit_pos[2] = hp.z;
-        r->dir[0] = dir.x;
-        r->dir[1] = dir.y;
-        r->dir[2] = dir.z;
-        r->thr[0] = thr.x;
-        r->thr[1] = thr.y;
-        r->thr[2] = thr.z;
-        r->u = h.u;
-        r->v = h.v;
-        r->key = key;
-        r->path = path;
-        r->id = h.slot >= 0 ? h.slot : ~h.sphere;
-        r->depth = depth;
-        r->pad = 0;
-        if (sc.has_emission) {
-          out.rad[e * 3] = rad.x;
-          out.rad[e * 3 + 1] = rad.y;
-          out.rad[e * 3 + 2] = rad.z;
-        }
+    break;
+  }
+
+  // append: hits at the front of this block's segment, unfinished rays at its back
+  if (STAGE != 2) {
+    unsigned long long* line = counters + (size_t)seg * RT_LINE_WORDS;
+    const unsigned long long hit_mask = __ballot(alive), ray_mask = __ballot(deferred);
+    size_t e = 0;
+    if (hit_mask) {
+      const uint32_t i = wave_reserve(&line[out.hit_word], hit_mask, lane);
+      if (alive) e = (size_t)seg * out.seg_cap + i;
+    }
+    if (ray_mask) {
+      const uint32_t i = wave_reserve(&line[out.ray_word], ray_mask, lane);
+      if (deferred) e = (size_t)seg * out.seg_cap + (out.seg_cap - 1u - i);
+    }
+    if (alive || deferred) {
+      QueueRec* r = out.recs + e;
+      const d3 p0 = alive ? o + h.t * dir : o;  // src/main.rs:831
+      r->hit_pos[0] = p0.x;
+      r->hit_pos[1] = p0.y;
+      r->hit_pos[2] = p0.z;
+      r->dir[0] = dir.x;
+      r->dir[1] = dir.y;
+      r->dir[2] = dir.z;
+      r->thr[0] = thr.x;
+      r->thr[1] = thr.y;
+      r->thr[2] = thr.z;
+      r->u = alive ? h.u : 0.0;
+      r->v = alive ? h.v : 0.0;
+      r->key = key;
+      r->path = path;
+      r->id = alive ? (h.slot >= 0 ? h.slot : ~h.sphere) : 0;
+      r->depth = depth;
+      r->pad = 0;
+      if (sc.has_emission) {
+        out.rad[e * 3] = rad.x;
+        out.rad[e * 3 + 1] = rad.y;
+        out.rad[e * 3 + 2] = rad.z;
       }
     }
-    break;
   }
   flush_counts(wc, counters, COUNT, n_done);
 }
@@ -853,7 +913,16 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
 
   const size_t lds = stack_lds_bytes(d);
   const double divisor = (double)(p->spp_total ? p->spp_total : p->spp);
-  const uint32_t tail_threshold = (uint32_t)env_mib("RT_TAIL_THRESHOLD", 32768);
+  const uint32_t tail_threshold = (uint32_t)env_mib("RT_TAIL_THRESHOLD", 262144);
+  const char* fuse_env = std::getenv("RT_FUSE_BOUNCES");
+  const uint32_t fuse_bounces = fuse_env && *fuse_env ? (uint32_t)std::max(0, std::atoi(fuse_env)) : 1u;
+  // RT_SHORT_STEPS=n > 0 turns the long-ray queue on: a scattered ray that needs more than n node
+  // visits is queued and traced by a later launch. Off by default: measured on MI355X it cuts
+  // the VALU instructions of a frame by 11 % but the long-ray launches wait on memory, and the
+  // frame gets 3-5 % slower.
+  const char* short_env = std::getenv("RT_SHORT_STEPS");
+  uint32_t short_steps = short_env && *short_env ? (uint32_t)std::max(0, std::atoi(short_env)) : 0u;
+  if (short_steps == 0) short_steps = 0x7fffffffu;
   int cus = 256;
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d->device);
   size_t n_events = 0;
@@ -912,6 +981,8 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
     pp.first_sample = p->first_sample + c * chunk;
     pp.n_paths = (uint32_t)(n_pix * pp.spp);
     pp.max_depth = p->max_depth;
+    pp.fuse_bounces = fuse_bounces;
+    pp.short_steps = short_steps;
     const uint32_t blocks_all = (pp.n_paths + RT_BLOCK - 1) / RT_BLOCK;
 
     if (mega) {
@@ -930,37 +1001,46 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
       }
       if ((rc = end_launch()) != RT_OK) return rc;
     } else {
-      // wavefront: stage 0 over all paths, then one launch per bounce over the survivors
+      // wavefront: stage 0 over all paths, then launches over the queued hits and long rays
       const uint32_t n_seg = choose_segments(pp.n_paths);
       const uint32_t seg_cap = ((blocks_all + n_seg - 1) / n_seg) * RT_BLOCK;
       QueueView qv[2];
-      for (int q = 0; q < 2; ++q) qv[q] = QueueView{(QueueRec*)d->queue[q], d->queue_rad[q], seg_cap, (uint32_t)(q ? CNT_Q1 : CNT_Q0)};
-      // both tails of every line start at zero (two adjacent words per line)
-      HIP_TRY(hipMemset2DAsync(d->counters + CNT_Q0, RT_LINE_WORDS * sizeof(unsigned long long), 0, 2 * sizeof(unsigned long long), RT_SHARDS, stream));
+      for (int q = 0; q < 2; ++q)
+        qv[q] = QueueView{(QueueRec*)d->queue[q], d->queue_rad[q], seg_cap, (uint32_t)(q ? CNT_Q1 : CNT_Q0), (uint32_t)(q ? CNT_R1 : CNT_R0)};
+      const size_t line_bytes = RT_LINE_WORDS * sizeof(unsigned long long);
+      // the four counts of every line start at zero (adjacent words)
+      HIP_TRY(hipMemset2DAsync(d->counters + CNT_Q0, line_bytes, 0, 4 * sizeof(unsigned long long), RT_SHARDS, stream));
       if ((rc = begin_launch(0, pp.n_paths)) != RT_OK) return rc;
-      if (count) hipLaunchKernelGGL((k_wave<true, 0>), dim3(blocks_all), dim3(RT_BLOCK), lds, stream, d->k, pp, qv[0], qv[0], n_seg, d->samples, d->counters);
-      else hipLaunchKernelGGL((k_wave<false, 0>), dim3(blocks_all), dim3(RT_BLOCK), lds, stream, d->k, pp, qv[0], qv[0], n_seg, d->samples, d->counters);
+      if (count) hipLaunchKernelGGL((k_wave<true, 0>), dim3(blocks_all), dim3(RT_BLOCK), lds, stream, d->k, pp, qv[0], qv[0], n_seg, 0u, d->samples, d->counters);
+      else hipLaunchKernelGGL((k_wave<false, 0>), dim3(blocks_all), dim3(RT_BLOCK), lds, stream, d->k, pp, qv[0], qv[0], n_seg, 0u, d->samples, d->counters);
       if ((rc = end_launch()) != RT_OK) return rc;
       int cur = 0;
       for (;;) {
         if ((rc = read_counters(d, stream, &now)) != RT_OK) return rc;
         account(d->launches.size() - 1);
-        const int tail_word = cur ? CNT_Q1 : CNT_Q0;
-        const uint64_t n_in = now.w[tail_word];
+        const int hit_word = cur ? CNT_Q1 : CNT_Q0, ray_word = cur ? CNT_R1 : CNT_R0;
+        const uint64_t n_in = now.w[hit_word] + now.w[ray_word];
         if (n_in == 0) break;
-        uint32_t max_seg = 0;
-        for (uint32_t sgi = 0; sgi < n_seg; ++sgi)
-          max_seg = std::max<uint32_t>(max_seg, (uint32_t)d->host_counters[(size_t)sgi * RT_LINE_WORDS + tail_word]);
-        if (max_seg > seg_cap || n_in > pp.n_paths) {
-          rt_set_error("%s: internal error: a queue segment holds %u records, capacity %u", who, max_seg, seg_cap);
+        uint32_t max_hit = 0, max_ray = 0;
+        bool overflow = false;
+        for (uint32_t sgi = 0; sgi < n_seg; ++sgi) {
+          const uint64_t nh = d->host_counters[(size_t)sgi * RT_LINE_WORDS + hit_word];
+          const uint64_t nr = d->host_counters[(size_t)sgi * RT_LINE_WORDS + ray_word];
+          overflow = overflow || nh + nr > seg_cap;
+          max_hit = std::max<uint32_t>(max_hit, (uint32_t)nh);
+          max_ray = std::max<uint32_t>(max_ray, (uint32_t)nr);
+        }
+        if (overflow || n_in > pp.n_paths) {
+          rt_set_error("%s: internal error: a queue segment holds more than its %u records", who, seg_cap);
           return RT_ERR_HIP;
         }
-        const dim3 grid(n_seg, (max_seg + RT_BLOCK - 1) / RT_BLOCK);
+        const uint32_t hit_blocks = (max_hit + RT_BLOCK - 1) / RT_BLOCK, ray_blocks = (max_ray + RT_BLOCK - 1) / RT_BLOCK;
+        const dim3 grid(n_seg, hit_blocks + ray_blocks);
         const int nxt = cur ^ 1;
         if (n_in <= tail_threshold) {
           if ((rc = begin_launch(2, (uint32_t)n_in)) != RT_OK) return rc;
-          if (count) hipLaunchKernelGGL((k_wave<true, 2>), grid, dim3(RT_BLOCK), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, d->samples, d->counters);
-          else hipLaunchKernelGGL((k_wave<false, 2>), grid, dim3(RT_BLOCK), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, d->samples, d->counters);
+          if (count) hipLaunchKernelGGL((k_wave<true, 2>), grid, dim3(RT_BLOCK), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, hit_blocks, d->samples, d->counters);
+          else hipLaunchKernelGGL((k_wave<false, 2>), grid, dim3(RT_BLOCK), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, hit_blocks, d->samples, d->counters);
           if ((rc = end_launch()) != RT_OK) return rc;
           if (count || timing) {
             if ((rc = read_counters(d, stream, &now)) != RT_OK) return rc;
@@ -968,10 +1048,10 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
           }
           break;
         }
-        HIP_TRY(hipMemset2DAsync(d->counters + (nxt ? CNT_Q1 : CNT_Q0), RT_LINE_WORDS * sizeof(unsigned long long), 0, sizeof(unsigned long long), RT_SHARDS, stream));
+        HIP_TRY(hipMemset2DAsync(d->counters + (nxt ? CNT_Q1 : CNT_Q0), line_bytes, 0, 2 * sizeof(unsigned long long), RT_SHARDS, stream));
         if ((rc = begin_launch(1, (uint32_t)n_in)) != RT_OK) return rc;
-        if (count) hipLaunchKernelGGL((k_wave<true, 1>), grid, dim3(RT_BLOCK), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, d->samples, d->counters);
-        else hipLaunchKernelGGL((k_wave<false, 1>), grid, dim3(RT_BLOCK), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, d->samples, d->counters);
+        if (count) hipLaunchKernelGGL((k_wave<true, 1>), grid, dim3(RT_BLOCK), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, hit_blocks, d->samples, d->counters);
+        else hipLaunchKernelGGL((k_wave<false, 1>), grid, dim3(RT_BLOCK), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, hit_blocks, d->samples, d->counters);
         if ((rc = end_launch()) != RT_OK) return rc;
         cur = nxt;
       }

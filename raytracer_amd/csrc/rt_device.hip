@@ -62,6 +62,19 @@ struct DeviceScene {
   size_t queue_rad_bytes[2] = {0, 0};
   unsigned long long* counters = nullptr;       // RT_SHARDS lines
   unsigned long long* host_counters = nullptr;  // pinned mirror
+  // Overlapped tails: when a call runs in several sample chunks, the thin tail of long paths of
+  // one chunk (and that chunk's resolve) runs on a side stream while the next chunk starts.
+  hipStream_t side = nullptr;
+  hipEvent_t ev_gathered[2] = {nullptr, nullptr};  // main stream: chunk's tail input is complete
+  hipEvent_t ev_resolved[2] = {nullptr, nullptr};  // side stream: chunk's samples have been summed
+  void* tail_in[2] = {nullptr, nullptr};           // compact tail input, one segment
+  size_t tail_in_bytes[2] = {0, 0};
+  double* tail_rad[2] = {nullptr, nullptr};
+  size_t tail_rad_bytes[2] = {0, 0};
+  unsigned long long* tail_counters = nullptr;     // counter lines of the side stream's kernels
+  unsigned long long* host_snaps = nullptr;        // pinned: tail_counters after each overlapped tail
+  size_t host_snaps_lines = 0;                     // capacity, in snapshots
+  bool side_used = false;                          // the last call ran kernels on the side stream
   // staging for the host-buffer entry points
   void* stage = nullptr;
   size_t stage_bytes = 0;
@@ -89,6 +102,15 @@ void rt_device_scene_free(DeviceScene* d) {
   if (d->samples) (void)hipFree(d->samples);
   if (d->totals) (void)hipFree(d->totals);
   if (d->counters) (void)hipFree(d->counters);
+  if (d->tail_counters) (void)hipFree(d->tail_counters);
+  if (d->host_snaps) (void)hipHostFree(d->host_snaps);
+  if (d->side) (void)hipStreamDestroy(d->side);
+  for (int q = 0; q < 2; ++q) {
+    if (d->ev_gathered[q]) (void)hipEventDestroy(d->ev_gathered[q]);
+    if (d->ev_resolved[q]) (void)hipEventDestroy(d->ev_resolved[q]);
+    if (d->tail_in[q]) (void)hipFree(d->tail_in[q]);
+    if (d->tail_rad[q]) (void)hipFree(d->tail_rad[q]);
+  }
   if (d->stage) (void)hipFree(d->stage);
   for (int q = 0; q < 2; ++q) {
     if (d->queue[q]) (void)hipFree(d->queue[q]);
@@ -175,6 +197,11 @@ extern "C" int rt_scene_upload(rt_scene* s, int device) {
     return fail(RT_ERR_HIP);
   }
   (void)hipMemset(d->counters, 0, RT_COUNTER_BYTES);
+  if (hipMalloc((void**)&d->tail_counters, RT_COUNTER_BYTES) != hipSuccess) {
+    rt_set_error("rt_scene_upload: hipMalloc of the side-stream counters failed");
+    return fail(RT_ERR_HIP);
+  }
+  (void)hipMemset(d->tail_counters, 0, RT_COUNTER_BYTES);
   if (hipHostMalloc((void**)&d->host_counters, RT_COUNTER_BYTES, hipHostMallocDefault) != hipSuccess) {
     rt_set_error("rt_scene_upload: hipHostMalloc of the counter mirror failed");
     return fail(RT_ERR_HIP);
@@ -214,12 +241,28 @@ static int ensure_bytes(void** p, size_t* have, size_t want) {
 struct CounterSums {
   unsigned long long w[CNT_N];
 };
+static void sum_lines(const unsigned long long* lines, CounterSums* sums) {
+  for (int s = 0; s < RT_SHARDS; ++s)
+    for (int w = 0; w < CNT_N; ++w) sums->w[w] += lines[(size_t)s * RT_LINE_WORDS + w];
+}
 static int read_counters(DeviceScene* d, hipStream_t stream, CounterSums* sums) {
   HIP_TRY(hipMemcpyAsync(d->host_counters, d->counters, RT_COUNTER_BYTES, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   std::memset(sums, 0, sizeof *sums);
-  for (int s = 0; s < RT_SHARDS; ++s)
-    for (int w = 0; w < CNT_N; ++w) sums->w[w] += d->host_counters[(size_t)s * RT_LINE_WORDS + w];
+  sum_lines(d->host_counters, sums);
+  return RT_OK;
+}
+// Work counters of a whole call: the main stream's lines plus the side stream's. Waits for both.
+static int read_call_counters(DeviceScene* d, hipStream_t stream, CounterSums* sums) {
+  if (d->side) HIP_TRY(hipStreamSynchronize(d->side));
+  int rc = read_counters(d, stream, sums);
+  if (rc != RT_OK || !d->side_used) return rc;
+  HIP_TRY(hipMemcpyAsync(d->host_counters, d->tail_counters, RT_COUNTER_BYTES, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  CounterSums t;
+  std::memset(&t, 0, sizeof t);
+  sum_lines(d->host_counters, &t);
+  for (int w : {CNT_RAYS, CNT_NODES, CNT_TRIS, CNT_SPHERES, CNT_SHADED, CNT_PATHS, CNT_WI_INNER, CNT_WI_LEAF, CNT_WI_REJECT, CNT_WAVES}) sums->w[w] += t.w[w];
   return RT_OK;
 }
 
@@ -717,6 +760,39 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
   flush_counts(wc, counters, COUNT, n_done);
 }
 
+// Copies the records still queued (hits at the front, rays at the back of every segment) into
+// one compact segment, whose two counts live in line 0 of `out_counters`. The tail kernel then
+// runs from that copy on the side stream while the main stream reuses the queues.
+__global__ __launch_bounds__(RT_BLOCK) void k_gather(QueueView in, QueueView out, uint32_t hit_blocks, int has_rad,
+                                                     const unsigned long long* __restrict__ in_counters, unsigned long long* out_counters) {
+  const uint32_t seg = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long* line = in_counters + (size_t)seg * RT_LINE_WORDS;
+  const bool ray_block = blockIdx.y >= hit_blocks;
+  bool alive;
+  size_t entry;
+  if (!ray_block) {
+    const uint32_t i = blockIdx.y * RT_BLOCK + threadIdx.x;
+    alive = i < (uint32_t)line[in.hit_word];
+    entry = (size_t)seg * in.seg_cap + i;
+  } else {
+    const uint32_t i = (blockIdx.y - hit_blocks) * RT_BLOCK + threadIdx.x;
+    alive = i < (uint32_t)line[in.ray_word];
+    entry = (size_t)seg * in.seg_cap + (in.seg_cap - 1u - (alive ? i : 0u));
+  }
+  const unsigned long long mask = __ballot(alive);
+  if (!mask) return;
+  const uint32_t i = wave_reserve(&out_counters[ray_block ? out.ray_word : out.hit_word], mask, lane);
+  if (!alive || i >= out.seg_cap) return;  // the host sized the segment for every record
+  const size_t e = ray_block ? (size_t)(out.seg_cap - 1u - i) : (size_t)i;
+  out.recs[e] = in.recs[entry];
+  if (has_rad) {
+    out.rad[e * 3] = in.rad[entry * 3];
+    out.rad[e * 3 + 1] = in.rad[entry * 3 + 1];
+    out.rad[e * 3 + 2] = in.rad[entry * 3 + 2];
+  }
+}
+
 // Sums a pixel's samples in sample order (src/main.rs:1020-1024). `totals` carries the running
 // sum between launches when a call is split into several sample chunks. On the last chunk the
 // mean is added to the canvas (src/main.rs:1029-1037), or the plain sum to an f32 buffer.
@@ -876,6 +952,7 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
   d->last_stream = stream;
   d->have_timing = false;
   d->launches.clear();
+  d->side_used = false;
   std::memset(&d->timing, 0, sizeof d->timing);
   HIP_TRY(hipMemsetAsync(d->counters, 0, RT_COUNTER_BYTES, stream));
   if (p->spp == 0) return RT_OK;
@@ -887,6 +964,7 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
   const bool mega = (p->flags & (RT_FLAG_MEGAKERNEL | RT_FLAG_NO_REGEN)) != 0;
   const bool regen = (p->flags & RT_FLAG_NO_REGEN) == 0;
   const bool emission = d->k.has_emission != 0;
+  const bool timing_or_count = timing || count;
 
   // Work buffers are bounded (RT_WORK_BUFFER_MIB); a call that needs more runs in sample chunks.
   const uint64_t n_pix = (uint64_t)tm.n_tiles * 64u;
@@ -898,10 +976,16 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
     rt_set_error("%s: image too large for one launch", who);
     return RT_ERR_INVALID;
   }
+  // A call in several chunks overlaps each chunk's tail with the next chunk, which takes a second
+  // sample buffer (24 B per path more).
+  const char* no_overlap = std::getenv("RT_NO_OVERLAP");
+  bool overlap = !mega && p->spp > chunk64 && !(no_overlap && *no_overlap);
+  if (overlap) chunk64 = std::max<uint64_t>(1, std::min<uint64_t>(budget / (n_pix * (per_path + 24u)), 0xfff00000ull / n_pix));
   const uint32_t chunk = (uint32_t)std::min<uint64_t>(p->spp, chunk64);
   const uint32_t n_chunks = (p->spp + chunk - 1) / chunk;
+  overlap = overlap && n_chunks > 1;
   const uint64_t cap = n_pix * chunk;  // paths per launch
-  if ((rc = ensure_bytes((void**)&d->samples, &d->samples_bytes, (size_t)cap * 24u)) != RT_OK) return rc;
+  if ((rc = ensure_bytes((void**)&d->samples, &d->samples_bytes, (size_t)cap * 24u * (overlap ? 2u : 1u))) != RT_OK) return rc;
   if (n_chunks > 1 && (rc = ensure_bytes((void**)&d->totals, &d->totals_bytes, (size_t)n_pix * 24u)) != RT_OK) return rc;
   if (!mega) {
     const uint64_t qe = queue_entries((uint32_t)cap);
@@ -910,10 +994,34 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
       if (emission && (rc = ensure_bytes((void**)&d->queue_rad[q], &d->queue_rad_bytes[q], (size_t)qe * 24u)) != RT_OK) return rc;
     }
   }
+  const uint32_t tail_threshold = (uint32_t)env_mib("RT_TAIL_THRESHOLD", 262144);
+  // one compact segment per parity holds a tail's input: a whole number of blocks of records
+  const uint32_t tail_cap = ((tail_threshold + RT_BLOCK - 1) / RT_BLOCK + 1) * RT_BLOCK;
+  if (overlap) {
+    if (!d->side) {
+      HIP_TRY(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
+      for (int q = 0; q < 2; ++q) {
+        HIP_TRY(hipEventCreateWithFlags(&d->ev_gathered[q], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&d->ev_resolved[q], hipEventDisableTiming));
+      }
+    }
+    for (int q = 0; q < 2; ++q) {
+      if ((rc = ensure_bytes(&d->tail_in[q], &d->tail_in_bytes[q], (size_t)tail_cap * sizeof(QueueRec))) != RT_OK) return rc;
+      if (emission && (rc = ensure_bytes((void**)&d->tail_rad[q], &d->tail_rad_bytes[q], (size_t)tail_cap * 24u)) != RT_OK) return rc;
+    }
+    if ((timing_or_count) && d->host_snaps_lines < n_chunks) {
+      if (d->host_snaps) (void)hipHostFree(d->host_snaps);
+      d->host_snaps = nullptr;
+      d->host_snaps_lines = 0;
+      HIP_TRY(hipHostMalloc((void**)&d->host_snaps, (size_t)n_chunks * RT_COUNTER_BYTES, hipHostMallocDefault));
+      d->host_snaps_lines = n_chunks;
+    }
+    HIP_TRY(hipMemsetAsync(d->tail_counters, 0, RT_COUNTER_BYTES, stream));
+    d->side_used = true;
+  }
 
   const size_t lds = stack_lds_bytes(d);
   const double divisor = (double)(p->spp_total ? p->spp_total : p->spp);
-  const uint32_t tail_threshold = (uint32_t)env_mib("RT_TAIL_THRESHOLD", 262144);
   const char* fuse_env = std::getenv("RT_FUSE_BOUNCES");
   const uint32_t fuse_bounces = fuse_env && *fuse_env ? (uint32_t)std::max(0, std::atoi(fuse_env)) : 1u;
   // RT_SHORT_STEPS=n > 0 turns the long-ray queue on: a scattered ray that needs more than n node
@@ -934,7 +1042,7 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
     size_t ev0;
   };
   std::vector<Pending> pending;
-  auto begin_launch = [&](uint32_t kind, uint32_t items) -> int {
+  auto begin_launch = [&](uint32_t kind, uint32_t items, hipStream_t on) -> int {
     rt_launch_info li;
     std::memset(&li, 0, sizeof li);
     li.kind = kind;
@@ -944,19 +1052,19 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
       hipEvent_t e;
       int r = event_at(d, n_events, &e);
       if (r != RT_OK) return r;
-      HIP_TRY(hipEventRecord(e, stream));
+      HIP_TRY(hipEventRecord(e, on));
       pending.push_back(Pending{d->launches.size() - 1, n_events});
       n_events += 2;
     }
     return RT_OK;
   };
-  auto end_launch = [&]() -> int {
+  auto end_launch = [&](hipStream_t on) -> int {
     HIP_TRY(hipGetLastError());
     if (timing) {
       hipEvent_t e;
       int r = event_at(d, pending.back().ev0 + 1, &e);
       if (r != RT_OK) return r;
-      HIP_TRY(hipEventRecord(e, stream));
+      HIP_TRY(hipEventRecord(e, on));
     }
     return RT_OK;
   };
@@ -972,6 +1080,12 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
     prev = now;
   };
 
+  struct TailSnap {  // an overlapped tail: its log entry and its snapshot of the side counters
+    size_t log_index;
+    uint32_t snap;
+  };
+  std::vector<TailSnap> tail_snaps;
+
   for (uint32_t c = 0; c < n_chunks; ++c) {
     PathParams pp;
     pp.cam = make_camera(p);
@@ -984,6 +1098,13 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
     pp.fuse_bounces = fuse_bounces;
     pp.short_steps = short_steps;
     const uint32_t blocks_all = (pp.n_paths + RT_BLOCK - 1) / RT_BLOCK;
+    // Every chunk but the last hands its tail and its resolve to the side stream.
+    const bool handoff = overlap && c + 1 < n_chunks;
+    const int par = (int)(c & 1u);
+    double* const samples = d->samples + (overlap ? (size_t)par * cap * 3u : 0u);
+    // this parity's sample buffer and tail input were last read by chunk c-2 on the side stream
+    if (overlap && c >= 2) HIP_TRY(hipStreamWaitEvent(stream, d->ev_resolved[par], 0));
+    hipStream_t resolve_on = stream;
 
     if (mega) {
       uint32_t grid = blocks_all;
@@ -991,15 +1112,15 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
         grid = std::min<uint32_t>(blocks_all, (uint32_t)cus * 8u);
         HIP_TRY(hipMemsetAsync(d->counters + CNT_WORK, 0, sizeof(unsigned long long), stream));
       }
-      if ((rc = begin_launch(3, pp.n_paths)) != RT_OK) return rc;
+      if ((rc = begin_launch(3, pp.n_paths, stream)) != RT_OK) return rc;
       if (regen) {
-        if (count) hipLaunchKernelGGL((k_paths<true, true>), dim3(grid), dim3(RT_BLOCK), lds, stream, d->k, pp, d->samples, d->counters);
-        else hipLaunchKernelGGL((k_paths<false, true>), dim3(grid), dim3(RT_BLOCK), lds, stream, d->k, pp, d->samples, d->counters);
+        if (count) hipLaunchKernelGGL((k_paths<true, true>), dim3(grid), dim3(RT_BLOCK), lds, stream, d->k, pp, samples, d->counters);
+        else hipLaunchKernelGGL((k_paths<false, true>), dim3(grid), dim3(RT_BLOCK), lds, stream, d->k, pp, samples, d->counters);
       } else {
-        if (count) hipLaunchKernelGGL((k_paths<true, false>), dim3(grid), dim3(RT_BLOCK), lds, stream, d->k, pp, d->samples, d->counters);
-        else hipLaunchKernelGGL((k_paths<false, false>), dim3(grid), dim3(RT_BLOCK), lds, stream, d->k, pp, d->samples, d->counters);
+        if (count) hipLaunchKernelGGL((k_paths<true, false>), dim3(grid), dim3(RT_BLOCK), lds, stream, d->k, pp, samples, d->counters);
+        else hipLaunchKernelGGL((k_paths<false, false>), dim3(grid), dim3(RT_BLOCK), lds, stream, d->k, pp, samples, d->counters);
       }
-      if ((rc = end_launch()) != RT_OK) return rc;
+      if ((rc = end_launch(stream)) != RT_OK) return rc;
     } else {
       // wavefront: stage 0 over all paths, then launches over the queued hits and long rays
       const uint32_t n_seg = choose_segments(pp.n_paths);
@@ -1010,10 +1131,10 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
       const size_t line_bytes = RT_LINE_WORDS * sizeof(unsigned long long);
       // the four counts of every line start at zero (adjacent words)
       HIP_TRY(hipMemset2DAsync(d->counters + CNT_Q0, line_bytes, 0, 4 * sizeof(unsigned long long), RT_SHARDS, stream));
-      if ((rc = begin_launch(0, pp.n_paths)) != RT_OK) return rc;
-      if (count) hipLaunchKernelGGL((k_wave<true, 0>), dim3(blocks_all), dim3(RT_BLOCK), lds, stream, d->k, pp, qv[0], qv[0], n_seg, 0u, d->samples, d->counters);
-      else hipLaunchKernelGGL((k_wave<false, 0>), dim3(blocks_all), dim3(RT_BLOCK), lds, stream, d->k, pp, qv[0], qv[0], n_seg, 0u, d->samples, d->counters);
-      if ((rc = end_launch()) != RT_OK) return rc;
+      if ((rc = begin_launch(0, pp.n_paths, stream)) != RT_OK) return rc;
+      if (count) hipLaunchKernelGGL((k_wave<true, 0>), dim3(blocks_all), dim3(RT_BLOCK), lds, stream, d->k, pp, qv[0], qv[0], n_seg, 0u, samples, d->counters);
+      else hipLaunchKernelGGL((k_wave<false, 0>), dim3(blocks_all), dim3(RT_BLOCK), lds, stream, d->k, pp, qv[0], qv[0], n_seg, 0u, samples, d->counters);
+      if ((rc = end_launch(stream)) != RT_OK) return rc;
       int cur = 0;
       for (;;) {
         if ((rc = read_counters(d, stream, &now)) != RT_OK) return rc;
@@ -1037,11 +1158,32 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
         const uint32_t hit_blocks = (max_hit + RT_BLOCK - 1) / RT_BLOCK, ray_blocks = (max_ray + RT_BLOCK - 1) / RT_BLOCK;
         const dim3 grid(n_seg, hit_blocks + ray_blocks);
         const int nxt = cur ^ 1;
+        if (n_in <= tail_threshold && handoff) {
+          // compact what is left into this parity's tail segment; the side stream takes it from there
+          const QueueView tv{(QueueRec*)d->tail_in[par], d->tail_rad[par], tail_cap, (uint32_t)(par ? CNT_Q1 : CNT_Q0), (uint32_t)(par ? CNT_R1 : CNT_R0)};
+          HIP_TRY(hipMemsetAsync(d->tail_counters + tv.hit_word, 0, 2 * sizeof(unsigned long long), stream));
+          hipLaunchKernelGGL(k_gather, grid, dim3(RT_BLOCK), 0, stream, qv[cur], tv, hit_blocks, (int)emission, d->counters, d->tail_counters);
+          HIP_TRY(hipGetLastError());
+          HIP_TRY(hipEventRecord(d->ev_gathered[par], stream));
+          HIP_TRY(hipStreamWaitEvent(d->side, d->ev_gathered[par], 0));
+          const uint32_t thb = (uint32_t)((now.w[hit_word] + RT_BLOCK - 1) / RT_BLOCK), trb = (uint32_t)((now.w[ray_word] + RT_BLOCK - 1) / RT_BLOCK);
+          if ((rc = begin_launch(2, (uint32_t)n_in, d->side)) != RT_OK) return rc;
+          if (count) hipLaunchKernelGGL((k_wave<true, 2>), dim3(1, thb + trb), dim3(RT_BLOCK), lds, d->side, d->k, pp, tv, tv, 1u, thb, samples, d->tail_counters);
+          else hipLaunchKernelGGL((k_wave<false, 2>), dim3(1, thb + trb), dim3(RT_BLOCK), lds, d->side, d->k, pp, tv, tv, 1u, thb, samples, d->tail_counters);
+          if ((rc = end_launch(d->side)) != RT_OK) return rc;
+          if (timing_or_count) {
+            const uint32_t snap = (uint32_t)tail_snaps.size();
+            HIP_TRY(hipMemcpyAsync(d->host_snaps + (size_t)snap * RT_SHARDS * RT_LINE_WORDS, d->tail_counters, RT_COUNTER_BYTES, hipMemcpyDeviceToHost, d->side));
+            tail_snaps.push_back(TailSnap{d->launches.size() - 1, snap});
+          }
+          resolve_on = d->side;
+          break;
+        }
         if (n_in <= tail_threshold) {
-          if ((rc = begin_launch(2, (uint32_t)n_in)) != RT_OK) return rc;
-          if (count) hipLaunchKernelGGL((k_wave<true, 2>), grid, dim3(RT_BLOCK), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, hit_blocks, d->samples, d->counters);
-          else hipLaunchKernelGGL((k_wave<false, 2>), grid, dim3(RT_BLOCK), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, hit_blocks, d->samples, d->counters);
-          if ((rc = end_launch()) != RT_OK) return rc;
+          if ((rc = begin_launch(2, (uint32_t)n_in, stream)) != RT_OK) return rc;
+          if (count) hipLaunchKernelGGL((k_wave<true, 2>), grid, dim3(RT_BLOCK), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, hit_blocks, samples, d->counters);
+          else hipLaunchKernelGGL((k_wave<false, 2>), grid, dim3(RT_BLOCK), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, hit_blocks, samples, d->counters);
+          if ((rc = end_launch(stream)) != RT_OK) return rc;
           if (count || timing) {
             if ((rc = read_counters(d, stream, &now)) != RT_OK) return rc;
             account(d->launches.size() - 1);
@@ -1049,18 +1191,45 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
           break;
         }
         HIP_TRY(hipMemset2DAsync(d->counters + (nxt ? CNT_Q1 : CNT_Q0), line_bytes, 0, 2 * sizeof(unsigned long long), RT_SHARDS, stream));
-        if ((rc = begin_launch(1, (uint32_t)n_in)) != RT_OK) return rc;
-        if (count) hipLaunchKernelGGL((k_wave<true, 1>), grid, dim3(RT_BLOCK), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, hit_blocks, d->samples, d->counters);
-        else hipLaunchKernelGGL((k_wave<false, 1>), grid, dim3(RT_BLOCK), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, hit_blocks, d->samples, d->counters);
-        if ((rc = end_launch()) != RT_OK) return rc;
+        if ((rc = begin_launch(1, (uint32_t)n_in, stream)) != RT_OK) return rc;
+        if (count) hipLaunchKernelGGL((k_wave<true, 1>), grid, dim3(RT_BLOCK), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, hit_blocks, samples, d->counters);
+        else hipLaunchKernelGGL((k_wave<false, 1>), grid, dim3(RT_BLOCK), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, hit_blocks, samples, d->counters);
+        if ((rc = end_launch(stream)) != RT_OK) return rc;
         cur = nxt;
       }
     }
+    // The running per-pixel totals pass from chunk to chunk in order: a handed-off chunk resolves
+    // on the side stream (after its tail); the last chunk resolves on the caller's stream after
+    // everything the side stream still holds.
+    if (handoff && resolve_on == stream) {  // the queue ran empty before the tail threshold
+      HIP_TRY(hipEventRecord(d->ev_gathered[par], stream));
+      HIP_TRY(hipStreamWaitEvent(d->side, d->ev_gathered[par], 0));
+      resolve_on = d->side;
+    }
+    if (overlap && !handoff) HIP_TRY(hipStreamWaitEvent(stream, d->ev_resolved[(c - 1) & 1u], 0));
     const uint32_t rgrid = (uint32_t)((n_pix + RT_BLOCK - 1) / RT_BLOCK);
-    if ((rc = begin_launch(4, (uint32_t)n_pix)) != RT_OK) return rc;
-    hipLaunchKernelGGL(k_resolve, dim3(rgrid), dim3(RT_BLOCK), 0, stream, tm, d->samples, pp.n_paths, pp.spp, d->totals,
+    if ((rc = begin_launch(4, (uint32_t)n_pix, resolve_on)) != RT_OK) return rc;
+    hipLaunchKernelGGL(k_resolve, dim3(rgrid), dim3(RT_BLOCK), 0, resolve_on, tm, samples, pp.n_paths, pp.spp, d->totals,
                        (int)(c == 0), (int)(c + 1 == n_chunks), divisor, d_canvas, d_sum);
-    if ((rc = end_launch()) != RT_OK) return rc;
+    if ((rc = end_launch(resolve_on)) != RT_OK) return rc;
+    if (handoff) HIP_TRY(hipEventRecord(d->ev_resolved[par], d->side));
+  }
+  if (!tail_snaps.empty()) {  // per-launch work of the overlapped tails, from their snapshots
+    HIP_TRY(hipStreamSynchronize(d->side));
+    CounterSums before{};
+    for (const TailSnap& ts : tail_snaps) {
+      CounterSums after{};
+      sum_lines(d->host_snaps + (size_t)ts.snap * RT_SHARDS * RT_LINE_WORDS, &after);
+      rt_launch_info& li = d->launches[ts.log_index];
+      li.rays = after.w[CNT_RAYS] - before.w[CNT_RAYS];
+      li.node_visits = after.w[CNT_NODES] - before.w[CNT_NODES];
+      li.tri_tests = after.w[CNT_TRIS] - before.w[CNT_TRIS];
+      li.waves = after.w[CNT_WAVES] - before.w[CNT_WAVES];
+      li.wave_iters_inner = after.w[CNT_WI_INNER] - before.w[CNT_WI_INNER];
+      li.wave_iters_leaf = after.w[CNT_WI_LEAF] - before.w[CNT_WI_LEAF];
+      li.wave_iters_reject = after.w[CNT_WI_REJECT] - before.w[CNT_WI_REJECT];
+      before = after;
+    }
   }
   if (timing) {
     HIP_TRY(hipStreamSynchronize(stream));
@@ -1108,7 +1277,7 @@ extern "C" int rt_render_accumulate(rt_scene* s, const rt_render_params* p, doub
   HIP_TRY(hipMemcpy(canvas, d->stage, bytes, hipMemcpyDeviceToHost));
   if (rays_out) {
     CounterSums cs;
-    if ((rc = read_counters(d, nullptr, &cs)) != RT_OK) return rc;
+    if ((rc = read_call_counters(d, nullptr, &cs)) != RT_OK) return rc;
     *rays_out = cs.w[CNT_RAYS];
   }
   return RT_OK;
@@ -1141,6 +1310,7 @@ extern "C" int rt_trace(rt_scene* s, const double* org3, const double* dir3, siz
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(out, d_hit, hit_bytes, hipMemcpyDeviceToHost));
   d->last_stream = nullptr;
+  d->side_used = false;
   return RT_OK;
 }
 
@@ -1176,6 +1346,7 @@ extern "C" int rt_primary_hits(rt_scene* s, const rt_render_params* p, int32_t* 
   HIP_TRY(hipMemcpy(obj, d_obj, npix * sizeof(int32_t), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(tri, d_tri, npix * sizeof(int32_t), hipMemcpyDeviceToHost));
   d->last_stream = nullptr;
+  d->side_used = false;
   return RT_OK;
 }
 
@@ -1191,7 +1362,7 @@ extern "C" int rt_scene_last_stats(rt_scene* s, rt_stats* out) {
   DeviceScene* d = s->dev;
   HIP_TRY(hipSetDevice(d->device));
   CounterSums cs;
-  int rc = read_counters(d, d->last_stream, &cs);
+  int rc = read_call_counters(d, d->last_stream, &cs);
   if (rc != RT_OK) return rc;
   out->rays = cs.w[CNT_RAYS];
   out->node_visits = cs.w[CNT_NODES];

@@ -203,13 +203,18 @@ def test_render_variants_are_bitwise_identical(gpu_scenes, monkeypatch):
                 {"RT_SHORT_STEPS": "0"},              # no long-ray queue: every ray traced at once
                 {"RT_SHORT_STEPS": "1", "RT_TAIL_THRESHOLD": "1"},  # nearly every scattered ray queued as a long ray
                 {"RT_SHORT_STEPS": "8", "RT_FUSE_BOUNCES": "0"},    # first stage queues its primary hits
-                {"RT_FUSE_BOUNCES": "3", "RT_WORK_BUFFER_MIB": "1"}):
+                {"RT_FUSE_BOUNCES": "3", "RT_WORK_BUFFER_MIB": "1"},
+                {"RT_WORK_BUFFER_MIB": "1", "RT_NO_OVERLAP": "1"},  # chunks one after the other, no side stream
+                {"RT_WORK_BUFFER_MIB": "2", "RT_TAIL_THRESHOLD": "300"}):  # overlapped tails, queues that empty before the threshold
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        for flags in (0, _ffi.RT_FLAG_MEGAKERNEL):
+        for flags in (0, _ffi.RT_FLAG_MEGAKERNEL, _ffi.RT_FLAG_COUNT_WORK | _ffi.RT_FLAG_TIMING):
             c = np.zeros((h, w, 3))
             assert s2.render(c, rt.render_params(width=w, height=h, spp=spp, seed=5, flags=flags)) == rays
             assert c.tobytes() == base.tobytes(), (env, flags)
+            if flags & _ffi.RT_FLAG_COUNT_WORK:
+                assert s2.last_stats().rays == rays and s2.last_stats().paths == w * h * spp
+                assert sum(l.rays for l in s2.last_launches()) == rays, env
         for k in env:
             monkeypatch.delenv(k)
 

@@ -89,18 +89,44 @@ def main():
         return parallel.weak_samples(p, rank, world) if world > 1 else p
 
     canvas = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda") if world == 1 else None
-    sum32 = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") if world > 1 else None
+    # N > 1: two sum buffers, so that the all-reduce of one frame runs (on the collective's own
+    # stream) while the next frame renders; a buffer is reused only after its reduction is done
+    sums = [torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(2)] if world > 1 else None
+    in_flight = [None, None]
+
+    debug = bool(os.environ.get("RT_BENCH_DEBUG"))
+
+    def note(msg):
+        if debug:
+            print(f"[rank {rank} {time.perf_counter():.3f}] {msg}", file=sys.stderr, flush=True)
 
     def run_step(step, flags):
+        note(f"step {step} flags {flags}")
         p = frame_params(step, flags)
         if world == 1:
             scene.render_device(canvas.data_ptr(), p, stream)
         else:
-            sum32.zero_()
-            scene.render_sum_f32_device(sum32.data_ptr(), p, stream)
-            parallel.reduce_frame_sum(sum32, dist)
+            b = step & 1
+            if in_flight[b] is not None:
+                in_flight[b].wait()
+            sums[b].zero_()
+            scene.render_sum_f32_device(sums[b].data_ptr(), p, stream)
+            note("rendered")
+            if os.environ.get("RT_BENCH_SYNC_REDUCE"):  # A/B: reduce each frame before the next starts
+                parallel.reduce_frame_sum(sums[b], dist)
+            else:
+                in_flight[b] = parallel.reduce_frame_sum(sums[b], dist, async_op=True)
+            note("reduce queued")
+
+    def drain():
+        for b in range(2):
+            if in_flight[b] is not None:
+                in_flight[b].wait()
+                in_flight[b] = None
+                note(f"drained {b}")
 
     def barrier():
+        drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -108,6 +134,7 @@ def main():
     # Work counters (node visits, triangle tests per ray, per kernel) from the counting build of
     # the kernels, on the first timed frame's parameters, outside the timed region.
     run_step(args.warmup, _ffi.RT_FLAG_COUNT_WORK)
+    drain()
     torch.cuda.synchronize()
     cst = scene.last_stats()
     per_ray = {

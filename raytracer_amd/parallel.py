@@ -42,13 +42,26 @@ def shard_tiles(params, rank, world, tile_size=64):
     return p
 
 
-def reduce_frame_sum(buf, dist, dst=None):
+def reduce_frame_sum(buf, dist, dst=None, async_op=False):
     """The exchange step of the sample split: sum the ranks' fp32 [H][W][3] buffers in place.
-    With dst=None every rank receives the sum (all-reduce); otherwise only rank dst does."""
+    With dst=None every rank receives the sum (all-reduce); otherwise only rank dst does.
+    async_op=True returns the collective's work handle (None when there is nothing to reduce):
+    the reduction then runs behind whatever the caller queues next, and `handle.wait()` orders
+    later work after it."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
-        return buf
+        return None if async_op else buf
+    if buf.is_cuda and dist.get_backend() == "gloo":
+        # rehearsal on a box with fewer GPUs than ranks: gloo reduces host memory, so stage the
+        # buffer through the host here (blocking) instead of leaving that to the backend
+        host = buf.cpu()
+        if dst is None:
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        else:
+            dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
+        buf.copy_(host)
+        return None if async_op else buf
     if dst is None:
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=async_op)
     else:
-        dist.reduce(buf, dst=dst, op=dist.ReduceOp.SUM)
-    return buf
+        work = dist.reduce(buf, dst=dst, op=dist.ReduceOp.SUM, async_op=async_op)
+    return work if async_op else buf

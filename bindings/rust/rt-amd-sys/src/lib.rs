@@ -24,6 +24,7 @@ pub const RT_FLAG_TIMING: u32 = 2;
 pub const RT_FLAG_COUNT_WORK: u32 = 4;
 pub const RT_FLAG_NO_REGEN: u32 = 8;
 pub const RT_FLAG_MEGAKERNEL: u32 = 16;
+pub const RT_FLAG_PIPELINE: u32 = 32;
 
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
@@ -194,6 +195,7 @@ extern "C" {
     pub fn rt_render_accumulate(scene: *mut rt_scene, p: *const rt_render_params, canvas: *mut f64, rays_out: *mut u64) -> c_int;
     pub fn rt_render_device(scene: *mut rt_scene, p: *const rt_render_params, device_canvas: *mut f64, stream: *mut c_void) -> c_int;
     pub fn rt_render_sum_f32_device(scene: *mut rt_scene, p: *const rt_render_params, device_sum: *mut f32, stream: *mut c_void) -> c_int;
+    pub fn rt_scene_wait(scene: *mut rt_scene) -> c_int;
     pub fn rt_scene_last_stats(scene: *mut rt_scene, out: *mut rt_stats) -> c_int;
     pub fn rt_scene_last_timing(scene: *mut rt_scene, out: *mut rt_timing) -> c_int;
     pub fn rt_scene_last_launches(scene: *mut rt_scene, out: *mut rt_launch_info, capacity: u32, n_out: *mut u32) -> c_int;

@@ -52,6 +52,15 @@ extern "C" {
 #define RT_FLAG_MEGAKERNEL 16u /* single persistent kernel with path regeneration (A/B); the  */
                               /* default is the wavefront form: one launch per bounce over a */
                               /* compacted ray queue                                         */
+#define RT_FLAG_PIPELINE 32u  /* rt_render_device / rt_render_sum_f32_device only: the call may  */
+                              /* return with its last kernels (the thin tail of long paths and   */
+                              /* the sum into the canvas) queued on a stream of the library's    */
+                              /* own instead of the caller's, so that they overlap the next      */
+                              /* call. The canvas is complete after rt_scene_wait (or any        */
+                              /* rt_scene_last_* call, or the next call without this flag).      */
+                              /* Consecutive pipelined calls on one stream form a run: their     */
+                              /* counters, launch log and timing accumulate. The reference's     */
+                              /* display loop (src/main.rs:1099-1112) is such a run.             */
 
 /* One per object, indexed by object index. Material::Opaque / Material::Dielectric,
  * src/main.rs:414-425; ColorKind src/main.rs:386-390; NormalKind src/main.rs:335-339. */
@@ -282,7 +291,11 @@ int rt_render_device(rt_scene* scene, const rt_render_params* p, double* device_
  * call's samples, as binary32 — the buffer a sum-reduction over ranks then combines. */
 int rt_render_sum_f32_device(rt_scene* scene, const rt_render_params* p, float* device_sum, void* stream);
 
-/* Waits for the scene's queued work, then reports. */
+/* Waits for everything the scene has queued, on the caller's stream and on the library's own. */
+int rt_scene_wait(rt_scene* scene);
+
+/* Waits for the scene's queued work, then reports (for a run of pipelined calls: the run's
+ * totals; the work of the overlapped tails is reported in total on the last tail of the log). */
 int rt_scene_last_stats(rt_scene* scene, rt_stats* out);
 int rt_scene_last_timing(rt_scene* scene, rt_timing* out);
 /* Per-launch log of the last render call: copies up to `capacity` entries, *n_out = total. */

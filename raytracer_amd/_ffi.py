@@ -26,6 +26,7 @@ RT_FLAG_TIMING = 2
 RT_FLAG_COUNT_WORK = 4
 RT_FLAG_NO_REGEN = 8
 RT_FLAG_MEGAKERNEL = 16
+RT_FLAG_PIPELINE = 32
 
 
 class rt_material(C.Structure):
@@ -179,6 +180,7 @@ SIGNATURES = {
     "rt_render_accumulate": (C.c_int, [_P, C.POINTER(rt_render_params), _P, C.POINTER(C.c_uint64)]),
     "rt_render_device": (C.c_int, [_P, C.POINTER(rt_render_params), _P, _P]),
     "rt_render_sum_f32_device": (C.c_int, [_P, C.POINTER(rt_render_params), _P, _P]),
+    "rt_scene_wait": (C.c_int, [_P]),
     "rt_scene_last_stats": (C.c_int, [_P, C.POINTER(rt_stats)]),
     "rt_scene_last_timing": (C.c_int, [_P, C.POINTER(rt_timing)]),
     "rt_scene_last_launches": (C.c_int, [_P, C.POINTER(rt_launch_info), C.c_uint32, C.POINTER(C.c_uint32)]),
@@ -187,12 +189,35 @@ SIGNATURES = {
 }
 
 
+def _share_torch_hip_runtime():
+    """A PyTorch-ROCm wheel carries its own libamdhip64.so, which torch's libraries ask for by file
+    name. If this library pulled in the system's copy first, a later `import torch` would load a
+    second HIP runtime into the process, and that one finds no GPU. Loading torch's copy (if there
+    is one) before librt_amd.so makes both resolve to the same runtime, whichever is imported
+    first. Does not import torch."""
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    for loc in (spec.submodule_search_locations or []) if spec else []:
+        cand = os.path.join(loc, "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+            return
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C raytracer_amd/csrc`). There is no fallback implementation."
         )
+    _share_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export the symbol

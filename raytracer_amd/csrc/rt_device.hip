@@ -75,6 +75,18 @@ struct DeviceScene {
   unsigned long long* host_snaps = nullptr;        // pinned: tail_counters after each overlapped tail
   size_t host_snaps_lines = 0;                     // capacity, in snapshots
   bool side_used = false;                          // the last call ran kernels on the side stream
+  // A run = one call, or consecutive RT_FLAG_PIPELINE calls, which share their accounting.
+  bool run_open = false;                           // the last call was pipelined
+  bool resolved_valid[2] = {false, false};         // ev_resolved[q] recorded since the side stream was last idle
+  uint32_t chunk_seq = 0;                          // chunks started so far: parity of the double buffers
+  unsigned long long prev_w[CNT_N] = {};           // main counters at the last host read of this run
+  struct Pending {                                 // a timed launch whose events have not been read yet
+    size_t log_index;
+    size_t ev0;
+  };
+  std::vector<Pending> pending;
+  size_t n_events = 0;
+  std::vector<size_t> lump_entries;                // log entries of pipelined tails (no snapshot)
   // staging for the host-buffer entry points
   void* stage = nullptr;
   size_t stage_bytes = 0;
@@ -83,6 +95,7 @@ struct DeviceScene {
   rt_timing timing{};
   bool have_timing = false;
   hipStream_t last_stream = nullptr;
+  bool last_stream_valid = false;
 };
 
 #define HIP_TRY(expr)                                                                          \
@@ -263,6 +276,56 @@ static int read_call_counters(DeviceScene* d, hipStream_t stream, CounterSums* s
   std::memset(&t, 0, sizeof t);
   sum_lines(d->host_counters, &t);
   for (int w : {CNT_RAYS, CNT_NODES, CNT_TRIS, CNT_SPHERES, CNT_SHADED, CNT_PATHS, CNT_WI_INNER, CNT_WI_LEAF, CNT_WI_REJECT, CNT_WAVES}) sums->w[w] += t.w[w];
+  return RT_OK;
+}
+
+// Reads the events of the timed launches recorded so far into the launch log (the caller has
+// waited for the streams they were recorded on).
+static int harvest_timing(DeviceScene* d) {
+  for (const DeviceScene::Pending& pe : d->pending) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, d->ev_pool[pe.ev0], d->ev_pool[pe.ev0 + 1]));
+    rt_launch_info& li = d->launches[pe.log_index];
+    li.ms = ms;
+    if (li.kind == 4) {
+      d->timing.ms_resolve += ms;
+      d->timing.resolve_launches++;
+    } else {
+      d->timing.ms_paths += ms;
+      d->timing.path_launches++;
+    }
+    d->have_timing = true;
+  }
+  d->pending.clear();
+  return RT_OK;
+}
+
+// Waits for everything the scene has queued on the caller's stream and on the side stream, then
+// completes the accounting of the run: launch durations, and the work of pipelined tails (whose
+// rays are known only in total and are reported on the last of them).
+static int finish_run(DeviceScene* d) {
+  HIP_TRY(hipSetDevice(d->device));
+  if (d->last_stream_valid) HIP_TRY(hipStreamSynchronize(d->last_stream));
+  if (d->side) HIP_TRY(hipStreamSynchronize(d->side));
+  d->resolved_valid[0] = d->resolved_valid[1] = false;
+  int rc = harvest_timing(d);
+  if (rc != RT_OK) return rc;
+  if (!d->lump_entries.empty()) {
+    HIP_TRY(hipMemcpy(d->host_counters, d->tail_counters, RT_COUNTER_BYTES, hipMemcpyDeviceToHost));
+    CounterSums t;
+    std::memset(&t, 0, sizeof t);
+    sum_lines(d->host_counters, &t);
+    rt_launch_info& li = d->launches[d->lump_entries.back()];
+    li.rays = t.w[CNT_RAYS];
+    li.node_visits = t.w[CNT_NODES];
+    li.tri_tests = t.w[CNT_TRIS];
+    li.waves = t.w[CNT_WAVES];
+    li.wave_iters_inner = t.w[CNT_WI_INNER];
+    li.wave_iters_leaf = t.w[CNT_WI_LEAF];
+    li.wave_iters_reject = t.w[CNT_WI_REJECT];
+    d->lump_entries.clear();
+  }
+  d->run_open = false;
   return RT_OK;
 }
 
@@ -949,19 +1012,34 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
     return RT_ERR_INVALID;
   }
   DeviceScene* d = s->dev;
+  const bool mega = (p->flags & (RT_FLAG_MEGAKERNEL | RT_FLAG_NO_REGEN)) != 0;
+  // RT_FLAG_PIPELINE: the call may return with its tail and resolve still queued on the side
+  // stream, so that the next call's first stage overlaps them. Consecutive pipelined calls on one
+  // stream form a run whose counters, launch log and timing accumulate.
+  const bool pipeline = (p->flags & RT_FLAG_PIPELINE) != 0 && !mega;
+  const bool continuing = pipeline && d->run_open && d->last_stream_valid && d->last_stream == stream;
+  if (!continuing) {
+    if (d->run_open && (rc = finish_run(d)) != RT_OK) return rc;  // an earlier run still holds the side stream
+    d->have_timing = false;
+    d->launches.clear();
+    d->pending.clear();
+    d->lump_entries.clear();
+    d->n_events = 0;
+    d->side_used = false;
+    std::memset(d->prev_w, 0, sizeof d->prev_w);
+    std::memset(&d->timing, 0, sizeof d->timing);
+    HIP_TRY(hipMemsetAsync(d->counters, 0, RT_COUNTER_BYTES, stream));
+    HIP_TRY(hipMemsetAsync(d->tail_counters, 0, RT_COUNTER_BYTES, stream));
+  }
   d->last_stream = stream;
-  d->have_timing = false;
-  d->launches.clear();
-  d->side_used = false;
-  std::memset(&d->timing, 0, sizeof d->timing);
-  HIP_TRY(hipMemsetAsync(d->counters, 0, RT_COUNTER_BYTES, stream));
+  d->last_stream_valid = true;
+  d->run_open = pipeline;
   if (p->spp == 0) return RT_OK;
 
   const TileMap tm = make_tilemap(p);
   if (tm.n_tiles == 0) return RT_OK;
   const bool timing = (p->flags & RT_FLAG_TIMING) != 0;
   const bool count = (p->flags & RT_FLAG_COUNT_WORK) != 0;
-  const bool mega = (p->flags & (RT_FLAG_MEGAKERNEL | RT_FLAG_NO_REGEN)) != 0;
   const bool regen = (p->flags & RT_FLAG_NO_REGEN) == 0;
   const bool emission = d->k.has_emission != 0;
   const bool timing_or_count = timing || count;
@@ -976,14 +1054,14 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
     rt_set_error("%s: image too large for one launch", who);
     return RT_ERR_INVALID;
   }
-  // A call in several chunks overlaps each chunk's tail with the next chunk, which takes a second
-  // sample buffer (24 B per path more).
+  // A call in several chunks overlaps each chunk's tail with the next chunk, and a pipelined call
+  // its last tail with the next call; both take a second sample buffer (24 B per path more).
   const char* no_overlap = std::getenv("RT_NO_OVERLAP");
-  bool overlap = !mega && p->spp > chunk64 && !(no_overlap && *no_overlap);
+  bool overlap = !mega && (pipeline || p->spp > chunk64) && !(no_overlap && *no_overlap);
   if (overlap) chunk64 = std::max<uint64_t>(1, std::min<uint64_t>(budget / (n_pix * (per_path + 24u)), 0xfff00000ull / n_pix));
   const uint32_t chunk = (uint32_t)std::min<uint64_t>(p->spp, chunk64);
   const uint32_t n_chunks = (p->spp + chunk - 1) / chunk;
-  overlap = overlap && n_chunks > 1;
+  overlap = overlap && (n_chunks > 1 || pipeline);
   const uint64_t cap = n_pix * chunk;  // paths per launch
   if ((rc = ensure_bytes((void**)&d->samples, &d->samples_bytes, (size_t)cap * 24u * (overlap ? 2u : 1u))) != RT_OK) return rc;
   if (n_chunks > 1 && (rc = ensure_bytes((void**)&d->totals, &d->totals_bytes, (size_t)n_pix * 24u)) != RT_OK) return rc;
@@ -1009,14 +1087,13 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
       if ((rc = ensure_bytes(&d->tail_in[q], &d->tail_in_bytes[q], (size_t)tail_cap * sizeof(QueueRec))) != RT_OK) return rc;
       if (emission && (rc = ensure_bytes((void**)&d->tail_rad[q], &d->tail_rad_bytes[q], (size_t)tail_cap * 24u)) != RT_OK) return rc;
     }
-    if ((timing_or_count) && d->host_snaps_lines < n_chunks) {
+    if (timing_or_count && !pipeline && d->host_snaps_lines < n_chunks) {
       if (d->host_snaps) (void)hipHostFree(d->host_snaps);
       d->host_snaps = nullptr;
       d->host_snaps_lines = 0;
       HIP_TRY(hipHostMalloc((void**)&d->host_snaps, (size_t)n_chunks * RT_COUNTER_BYTES, hipHostMallocDefault));
       d->host_snaps_lines = n_chunks;
     }
-    HIP_TRY(hipMemsetAsync(d->tail_counters, 0, RT_COUNTER_BYTES, stream));
     d->side_used = true;
   }
 
@@ -1033,15 +1110,9 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
   if (short_steps == 0) short_steps = 0x7fffffffu;
   int cus = 256;
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d->device);
-  size_t n_events = 0;
-  CounterSums prev{}, now{};
+  CounterSums now{};
 
   // Launch log; with timing every launch is bracketed by two events of the pool.
-  struct Pending {
-    size_t log_index;
-    size_t ev0;
-  };
-  std::vector<Pending> pending;
   auto begin_launch = [&](uint32_t kind, uint32_t items, hipStream_t on) -> int {
     rt_launch_info li;
     std::memset(&li, 0, sizeof li);
@@ -1050,11 +1121,11 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
     d->launches.push_back(li);
     if (timing) {
       hipEvent_t e;
-      int r = event_at(d, n_events, &e);
+      int r = event_at(d, d->n_events, &e);
       if (r != RT_OK) return r;
       HIP_TRY(hipEventRecord(e, on));
-      pending.push_back(Pending{d->launches.size() - 1, n_events});
-      n_events += 2;
+      d->pending.push_back(DeviceScene::Pending{d->launches.size() - 1, d->n_events});
+      d->n_events += 2;
     }
     return RT_OK;
   };
@@ -1062,22 +1133,22 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
     HIP_TRY(hipGetLastError());
     if (timing) {
       hipEvent_t e;
-      int r = event_at(d, pending.back().ev0 + 1, &e);
+      int r = event_at(d, d->pending.back().ev0 + 1, &e);
       if (r != RT_OK) return r;
       HIP_TRY(hipEventRecord(e, on));
     }
     return RT_OK;
   };
-  auto account = [&](size_t log_index) {  // counters are cumulative over the call
+  auto account = [&](size_t log_index) {  // the main counters are cumulative over the run
     rt_launch_info& li = d->launches[log_index];
-    li.rays = now.w[CNT_RAYS] - prev.w[CNT_RAYS];
-    li.node_visits = now.w[CNT_NODES] - prev.w[CNT_NODES];
-    li.tri_tests = now.w[CNT_TRIS] - prev.w[CNT_TRIS];
-    li.waves = now.w[CNT_WAVES] - prev.w[CNT_WAVES];
-    li.wave_iters_inner = now.w[CNT_WI_INNER] - prev.w[CNT_WI_INNER];
-    li.wave_iters_leaf = now.w[CNT_WI_LEAF] - prev.w[CNT_WI_LEAF];
-    li.wave_iters_reject = now.w[CNT_WI_REJECT] - prev.w[CNT_WI_REJECT];
-    prev = now;
+    li.rays = now.w[CNT_RAYS] - d->prev_w[CNT_RAYS];
+    li.node_visits = now.w[CNT_NODES] - d->prev_w[CNT_NODES];
+    li.tri_tests = now.w[CNT_TRIS] - d->prev_w[CNT_TRIS];
+    li.waves = now.w[CNT_WAVES] - d->prev_w[CNT_WAVES];
+    li.wave_iters_inner = now.w[CNT_WI_INNER] - d->prev_w[CNT_WI_INNER];
+    li.wave_iters_leaf = now.w[CNT_WI_LEAF] - d->prev_w[CNT_WI_LEAF];
+    li.wave_iters_reject = now.w[CNT_WI_REJECT] - d->prev_w[CNT_WI_REJECT];
+    std::memcpy(d->prev_w, now.w, sizeof d->prev_w);
   };
 
   struct TailSnap {  // an overlapped tail: its log entry and its snapshot of the side counters
@@ -1098,12 +1169,13 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
     pp.fuse_bounces = fuse_bounces;
     pp.short_steps = short_steps;
     const uint32_t blocks_all = (pp.n_paths + RT_BLOCK - 1) / RT_BLOCK;
-    // Every chunk but the last hands its tail and its resolve to the side stream.
-    const bool handoff = overlap && c + 1 < n_chunks;
-    const int par = (int)(c & 1u);
-    double* const samples = d->samples + (overlap ? (size_t)par * cap * 3u : 0u);
-    // this parity's sample buffer and tail input were last read by chunk c-2 on the side stream
-    if (overlap && c >= 2) HIP_TRY(hipStreamWaitEvent(stream, d->ev_resolved[par], 0));
+    // Every chunk but the last hands its tail and its resolve to the side stream; so does the
+    // last chunk of a pipelined call.
+    const bool handoff = overlap && (c + 1 < n_chunks || pipeline);
+    const int par = overlap ? (int)(d->chunk_seq++ & 1u) : 0;
+    double* const samples = d->samples + (overlap ? (size_t)par * (d->samples_bytes / 16u) : 0u);
+    // this parity's sample buffer and tail input were last read two chunks ago on the side stream
+    if (overlap && d->resolved_valid[par]) HIP_TRY(hipStreamWaitEvent(stream, d->ev_resolved[par], 0));
     hipStream_t resolve_on = stream;
 
     if (mega) {
@@ -1171,7 +1243,9 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
           if (count) hipLaunchKernelGGL((k_wave<true, 2>), dim3(1, thb + trb), dim3(RT_BLOCK), lds, d->side, d->k, pp, tv, tv, 1u, thb, samples, d->tail_counters);
           else hipLaunchKernelGGL((k_wave<false, 2>), dim3(1, thb + trb), dim3(RT_BLOCK), lds, d->side, d->k, pp, tv, tv, 1u, thb, samples, d->tail_counters);
           if ((rc = end_launch(d->side)) != RT_OK) return rc;
-          if (timing_or_count) {
+          if (pipeline) {
+            d->lump_entries.push_back(d->launches.size() - 1);
+          } else if (timing_or_count) {
             const uint32_t snap = (uint32_t)tail_snaps.size();
             HIP_TRY(hipMemcpyAsync(d->host_snaps + (size_t)snap * RT_SHARDS * RT_LINE_WORDS, d->tail_counters, RT_COUNTER_BYTES, hipMemcpyDeviceToHost, d->side));
             tail_snaps.push_back(TailSnap{d->launches.size() - 1, snap});
@@ -1206,13 +1280,16 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
       HIP_TRY(hipStreamWaitEvent(d->side, d->ev_gathered[par], 0));
       resolve_on = d->side;
     }
-    if (overlap && !handoff) HIP_TRY(hipStreamWaitEvent(stream, d->ev_resolved[(c - 1) & 1u], 0));
+    if (overlap && !handoff && d->resolved_valid[par ^ 1]) HIP_TRY(hipStreamWaitEvent(stream, d->ev_resolved[par ^ 1], 0));
     const uint32_t rgrid = (uint32_t)((n_pix + RT_BLOCK - 1) / RT_BLOCK);
     if ((rc = begin_launch(4, (uint32_t)n_pix, resolve_on)) != RT_OK) return rc;
     hipLaunchKernelGGL(k_resolve, dim3(rgrid), dim3(RT_BLOCK), 0, resolve_on, tm, samples, pp.n_paths, pp.spp, d->totals,
                        (int)(c == 0), (int)(c + 1 == n_chunks), divisor, d_canvas, d_sum);
     if ((rc = end_launch(resolve_on)) != RT_OK) return rc;
-    if (handoff) HIP_TRY(hipEventRecord(d->ev_resolved[par], d->side));
+    if (handoff) {
+      HIP_TRY(hipEventRecord(d->ev_resolved[par], d->side));
+      d->resolved_valid[par] = true;
+    }
   }
   if (!tail_snaps.empty()) {  // per-launch work of the overlapped tails, from their snapshots
     HIP_TRY(hipStreamSynchronize(d->side));
@@ -1231,22 +1308,9 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
       before = after;
     }
   }
-  if (timing) {
+  if (timing && !pipeline) {
     HIP_TRY(hipStreamSynchronize(stream));
-    for (const Pending& pe : pending) {
-      float ms = 0.f;
-      HIP_TRY(hipEventElapsedTime(&ms, d->ev_pool[pe.ev0], d->ev_pool[pe.ev0 + 1]));
-      rt_launch_info& li = d->launches[pe.log_index];
-      li.ms = ms;
-      if (li.kind == 4) {
-        d->timing.ms_resolve += ms;
-        d->timing.resolve_launches++;
-      } else {
-        d->timing.ms_paths += ms;
-        d->timing.path_launches++;
-      }
-    }
-    d->have_timing = true;
+    if ((rc = harvest_timing(d)) != RT_OK) return rc;
   }
   return RT_OK;
 }
@@ -1273,6 +1337,7 @@ extern "C" int rt_render_accumulate(rt_scene* s, const rt_render_params* p, doub
   HIP_TRY(hipMemcpy(d->stage, canvas, bytes, hipMemcpyHostToDevice));
   rc = render_impl(s, p, (double*)d->stage, nullptr, nullptr, "rt_render_accumulate");
   if (rc != RT_OK) return rc;
+  if ((rc = finish_run(d)) != RT_OK) return rc;
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(canvas, d->stage, bytes, hipMemcpyDeviceToHost));
   if (rays_out) {
@@ -1296,6 +1361,8 @@ extern "C" int rt_trace(rt_scene* s, const double* org3, const double* dir3, siz
     return RT_ERR_INVALID;
   }
   DeviceScene* d = s->dev;
+  if ((rc = finish_run(d)) != RT_OK) return rc;
+  HIP_TRY(hipDeviceSynchronize());
   const size_t ray_bytes = n * 3 * sizeof(double), hit_bytes = n * sizeof(rt_hit);
   if ((rc = ensure_bytes(&d->stage, &d->stage_bytes, 2 * ray_bytes + hit_bytes)) != RT_OK) return rc;
   double* d_org = (double*)d->stage;
@@ -1310,6 +1377,7 @@ extern "C" int rt_trace(rt_scene* s, const double* org3, const double* dir3, siz
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(out, d_hit, hit_bytes, hipMemcpyDeviceToHost));
   d->last_stream = nullptr;
+  d->last_stream_valid = true;
   d->side_used = false;
   return RT_OK;
 }
@@ -1323,6 +1391,8 @@ extern "C" int rt_primary_hits(rt_scene* s, const rt_render_params* p, int32_t* 
     return RT_ERR_INVALID;
   }
   DeviceScene* d = s->dev;
+  if ((rc = finish_run(d)) != RT_OK) return rc;
+  HIP_TRY(hipDeviceSynchronize());
   const size_t npix = (size_t)p->width * p->height;
   const size_t bytes = npix * (2 * sizeof(int32_t) + 3 * sizeof(double));
   if ((rc = ensure_bytes(&d->stage, &d->stage_bytes, bytes)) != RT_OK) return rc;
@@ -1346,8 +1416,18 @@ extern "C" int rt_primary_hits(rt_scene* s, const rt_render_params* p, int32_t* 
   HIP_TRY(hipMemcpy(obj, d_obj, npix * sizeof(int32_t), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(tri, d_tri, npix * sizeof(int32_t), hipMemcpyDeviceToHost));
   d->last_stream = nullptr;
+  d->last_stream_valid = true;
   d->side_used = false;
   return RT_OK;
+}
+
+extern "C" int rt_scene_wait(rt_scene* s) {
+  if (!s) {
+    rt_set_error("rt_scene_wait: null scene");
+    return RT_ERR_INVALID;
+  }
+  if (!s->dev) return RT_OK;
+  return finish_run(s->dev);
 }
 
 extern "C" int rt_scene_last_stats(rt_scene* s, rt_stats* out) {
@@ -1360,10 +1440,10 @@ extern "C" int rt_scene_last_stats(rt_scene* s, rt_stats* out) {
     return RT_ERR_NO_DEVICE;
   }
   DeviceScene* d = s->dev;
-  HIP_TRY(hipSetDevice(d->device));
-  CounterSums cs;
-  int rc = read_call_counters(d, d->last_stream, &cs);
+  int rc = finish_run(d);
   if (rc != RT_OK) return rc;
+  CounterSums cs;
+  if ((rc = read_call_counters(d, d->last_stream, &cs)) != RT_OK) return rc;
   out->rays = cs.w[CNT_RAYS];
   out->node_visits = cs.w[CNT_NODES];
   out->tri_tests = cs.w[CNT_TRIS];
@@ -1382,6 +1462,7 @@ extern "C" int rt_scene_last_timing(rt_scene* s, rt_timing* out) {
     rt_set_error("rt_scene_last_timing: null argument");
     return RT_ERR_INVALID;
   }
+  if (s->dev && finish_run(s->dev) != RT_OK) return RT_ERR_HIP;
   if (!s->dev || !s->dev->have_timing) {
     rt_set_error("rt_scene_last_timing: the last call was not made with RT_FLAG_TIMING");
     return RT_ERR_INVALID;
@@ -1399,6 +1480,7 @@ extern "C" int rt_scene_last_launches(rt_scene* s, rt_launch_info* out, uint32_t
     rt_set_error("rt_scene_last_launches: the scene has not been uploaded");
     return RT_ERR_NO_DEVICE;
   }
+  if (finish_run(s->dev) != RT_OK) return RT_ERR_HIP;
   const std::vector<rt_launch_info>& l = s->dev->launches;
   *n_out = (uint32_t)l.size();
   for (uint32_t i = 0; i < capacity && i < l.size(); ++i) out[i] = l[i];

@@ -126,11 +126,20 @@ int main(int argc, char** argv) {
   for (uint32_t it = 0; it < its; ++it) {
     rt_render_params q = p;
     q.first_sample = p.first_sample + it * p.spp;  // fresh samples of each pixel's stream per call
+    // frame follows frame: let each call's last kernels overlap the next call (a pipelined run)
+    q.flags |= RT_FLAG_PIPELINE;
     if (rt_render_device(scene, &q, canvas, stream) != RT_OK) return die("rt_render_device");
+    if (progress) {  // showing a frame ends the run: wait, count its rays, write it
+      rt_stats st;
+      if (rt_scene_last_stats(scene, &st) != RT_OK) return die("rt_scene_last_stats");
+      rays += st.rays;
+      if (write_frame(out_path.c_str(), canvas, host, rgba, p.width, p.height, it + 1, stream)) return 1;
+    }
+  }
+  if (!progress) {  // waits for the run and reports its totals
     rt_stats st;
     if (rt_scene_last_stats(scene, &st) != RT_OK) return die("rt_scene_last_stats");
-    rays += st.rays;
-    if (progress && write_frame(out_path.c_str(), canvas, host, rgba, p.width, p.height, it + 1, stream)) return 1;
+    rays = st.rays;
   }
   if (hipStreamSynchronize(stream) != hipSuccess) {
     std::fprintf(stderr, "rt_render: the render stream failed\n");

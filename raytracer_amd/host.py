@@ -287,6 +287,10 @@ class Scene:
     def render_sum_f32_device(self, device_sum_ptr, params, stream=None):
         check(lib.rt_render_sum_f32_device(self._h, C.byref(params), C.c_void_p(device_sum_ptr), C.c_void_p(stream or 0)), "rt_render_sum_f32_device")
 
+    def wait(self):
+        """Waits for everything the scene has queued (ends a run of pipelined calls)."""
+        check(lib.rt_scene_wait(self._h), "rt_scene_wait")
+
     def last_stats(self):
         s = _ffi.rt_stats()
         check(lib.rt_scene_last_stats(self._h, C.byref(s)), "rt_scene_last_stats")

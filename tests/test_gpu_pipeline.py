@@ -1,0 +1,85 @@
+"""RT_FLAG_PIPELINE: a run of calls whose tails and canvas sums overlap the next call must leave
+the same bits in the canvas, and the same totals in the counters, as the calls made one by one."""
+import numpy as np
+import pytest
+
+import raytracer_amd as rt
+from raytracer_amd import _ffi, scenes
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+W, H, SPP, ITS = 96, 72, 3, 5
+
+
+def frame(i, flags=0, **kw):
+    return rt.render_params(width=W, height=H, spp=SPP, first_sample=i * SPP, seed=3, flags=flags, **kw)
+
+
+@pytest.fixture(scope="module")
+def spot():
+    if rt.device_count() < 1:
+        pytest.fail("no HIP device visible")
+    s = scenes.build("spot")
+    s.upload(0)
+    return s
+
+
+@pytest.fixture(scope="module")
+def one_by_one(spot):
+    c = np.zeros((H, W, 3))
+    rays = [spot.render(c, frame(i)) for i in range(ITS)]
+    return c, rays
+
+
+@pytest.mark.parametrize("env", [{}, {"RT_TAIL_THRESHOLD": "500"}, {"RT_WORK_BUFFER_MIB": "1"},
+                                 {"RT_WORK_BUFFER_MIB": "1", "RT_TAIL_THRESHOLD": "200"}, {"RT_NO_OVERLAP": "1"}])
+def test_pipelined_run_equals_calls_one_by_one(spot, one_by_one, monkeypatch, env):
+    want, rays = one_by_one
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    canvas = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    for i in range(ITS):
+        spot.render_device(canvas.data_ptr(), frame(i, _ffi.RT_FLAG_PIPELINE | _ffi.RT_FLAG_TIMING), stream)
+    spot.wait()
+    assert canvas.cpu().numpy().tobytes() == want.tobytes()
+    st = spot.last_stats()  # the run's totals
+    assert st.rays == sum(rays)
+    log = spot.last_launches()
+    assert sum(1 for l in log if l.kind == 0) >= ITS and sum(1 for l in log if l.kind == 4) >= ITS
+    assert sum(l.rays for l in log) == sum(rays)
+    tm = spot.last_timing()
+    assert tm.path_launches + tm.resolve_launches == len(log) and tm.ms_paths > 0.0
+
+
+def test_run_ends_at_a_plain_call_and_at_a_stats_call(spot, one_by_one):
+    want, rays = one_by_one
+    canvas = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    spot.render_device(canvas.data_ptr(), frame(0, _ffi.RT_FLAG_PIPELINE), stream)
+    spot.render_device(canvas.data_ptr(), frame(1, _ffi.RT_FLAG_PIPELINE), stream)
+    assert spot.last_stats().rays == rays[0] + rays[1]  # waits, ends the run
+    spot.render_device(canvas.data_ptr(), frame(2, _ffi.RT_FLAG_PIPELINE), stream)
+    spot.render_device(canvas.data_ptr(), frame(3), stream)  # plain: ordered after the run, on the caller's stream
+    torch.cuda.current_stream().synchronize()
+    assert spot.last_stats().rays == rays[3]
+    spot.render_device(canvas.data_ptr(), frame(4, _ffi.RT_FLAG_PIPELINE | _ffi.RT_FLAG_COUNT_WORK), stream)
+    st = spot.last_stats()
+    assert st.rays == rays[4] and st.paths == W * H * SPP and st.node_visits > st.rays
+    assert canvas.cpu().numpy().tobytes() == want.tobytes()
+
+
+def test_pipelined_f32_sums_and_host_entry_point(spot, one_by_one):
+    want, rays = one_by_one
+    acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    ref = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    for i in range(ITS):
+        spot.render_sum_f32_device(ref.data_ptr(), frame(i), stream)
+        spot.render_sum_f32_device(acc.data_ptr(), frame(i, _ffi.RT_FLAG_PIPELINE), stream)
+    spot.wait()
+    assert torch.equal(acc, ref)
+    c = np.zeros((H, W, 3))  # the blocking entry point accepts the flag and still returns a finished canvas
+    assert [spot.render(c, frame(i, _ffi.RT_FLAG_PIPELINE)) for i in range(ITS)] == rays
+    assert c.tobytes() == want.tobytes()

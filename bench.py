@@ -158,7 +158,7 @@ def main():
     # as in the reference's display loop where frame follows frame; rt_scene_wait at the end is
     # inside the timed region. With N > 1 every frame ends in a reduction, so frames are ordered
     # on the stream and only the reduction overlaps the next frame.
-    pipelined = world == 1 and not os.environ.get("RT_BENCH_NO_PIPELINE")
+    pipelined = world == 1 and args.form == "wave" and not os.environ.get("RT_BENCH_NO_PIPELINE")
     step_flags = _ffi.RT_FLAG_TIMING | (_ffi.RT_FLAG_PIPELINE if pipelined else 0)
     rays_total = 0
     timed = {}  # kernel kind -> [ms, launches, rays]

@@ -634,8 +634,14 @@ __device__ __forceinline__ void camera_ray(const CameraK& cam, uint32_t u, uint3
   }
   const double p_x = (2.0 * (((double)u + 0.5 + x_offset) / (double)cam.width) - 1.0) * cam.tan_half * cam.aspect;
   const double p_y = (1.0 - 2.0 * (((double)v + 0.5 + y_offset) / (double)cam.height)) * cam.tan_half;
-  const double ox = rng.range(-cam.dof, cam.dof);
-  const double oy = rng.range(-cam.dof, cam.dof);
+  // src/main.rs:1007-1008. With DOF_STRENGTH = 0 (the reference's setting) both draws give
+  // -0 + 0*u = +0 whatever u is, so the two generator calls are skipped: they are the camera
+  // stage's last draws, and every later stage of the path starts its own counter.
+  double ox = 0.0, oy = 0.0;
+  if (cam.dof != 0.0) {
+    ox = rng.range(-cam.dof, cam.dof);
+    oy = rng.range(-cam.dof, cam.dof);
+  }
   o = mk(ox, oy, 0.0);
   const d3 d = 2.4 * normalize(mk(p_x, p_y, -1.0));
   dir = normalize(d - o);

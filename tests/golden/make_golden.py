@@ -10,6 +10,10 @@ Fixtures
                                      of the reference that pins the oracle end to end.
   primary_<scene>_<w>x<h>.npz        primary-hit buffer of the oracle (brute-force Scene::hit on
                                      pixel-centre rays): sha256 of obj/tri/t/u/v plus a 16x16 crop.
+  render_<scene>.npz                 the oracle's image (binary64 canvas) and ray count for a small
+                                     render of each scene with the shared counter-based sampler:
+                                     the vector the GPU path is held to (1e-12 relative) and
+                                     that pins the oracle itself against drift (bitwise).
   kat.json                           analytic known-answer vectors (values derived by hand from
                                      the formulas of src/main.rs, not produced by the oracle).
 """
@@ -57,6 +61,27 @@ def primary(scene_name, w, h):
         crop=crop, crop_origin=np.array([y0, x0]), hit_fraction=float((hit["obj"] >= 0).mean()),
     )
     print(f"wrote primary_{scene_name}_{w}x{h}.npz  hit fraction {(hit['obj'] >= 0).mean():.4f}")
+
+
+RENDERS = {  # scene: (width, height, spp, seed)
+    "spot": (48, 36, 2, 11),
+    "lens": (40, 30, 2, 12),
+    "sphere_floor": (48, 27, 3, 13),
+    "ogre": (40, 22, 2, 14),
+}
+
+
+def render(scene_name):
+    import oracle_ffi as orc
+    import raytracer_amd as rt
+
+    w, h, spp, seed = RENDERS[scene_name]
+    s = orc.OracleScene.build(scene_name)
+    c = np.zeros((h, w, 3))
+    rays, _ = s.render(c, rt.render_params(width=w, height=h, spp=spp, seed=seed))
+    np.savez_compressed(os.path.join(HERE, f"render_{scene_name}.npz"), canvas=c, rays=np.uint64(rays),
+                        params=np.array([w, h, spp, seed], dtype=np.int64))
+    print(f"wrote render_{scene_name}.npz  {rays} rays, mean {c.mean():.4f}")
 
 
 def kat():
@@ -129,3 +154,5 @@ if __name__ == "__main__":
     primary("spot", 1600, 1200)
     primary("sphere_floor", 192, 108)
     primary("ogre", 160, 90)
+    for name in RENDERS:
+        render(name)

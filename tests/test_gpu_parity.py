@@ -157,6 +157,17 @@ def test_render_matches_oracle(gpu_scenes, oracle, name, w, h, spp):
     assert c.mean() > 0.1
 
 
+@pytest.mark.parametrize("name", ["spot", "lens", "sphere_floor", "ogre"])
+def test_render_matches_committed_vectors(gpu_scenes, name):
+    """Against the fixtures alone (tests/golden/render_*.npz: the oracle's image and ray count)."""
+    g = np.load(os.path.join(HERE, "golden", f"render_{name}.npz"))
+    w, h, spp, seed = (int(x) for x in g["params"])
+    c = np.zeros((h, w, 3))
+    rays = gpu_scenes(name).render(c, rt.render_params(width=w, height=h, spp=spp, seed=seed))
+    assert rays == int(g["rays"])
+    assert rel_err(c, g["canvas"]) < IMG_RTOL
+
+
 def test_render_accumulates_and_is_progressive(gpu_scenes, oracle):
     """render adds into the canvas (src/main.rs:1035-1037); successive frames use successive
     samples; frames of spp a and b equal one frame's sample streams a+b."""

@@ -167,3 +167,17 @@ def test_screenshot_pin(oracle):
     for ch in range(3):
         assert np.corrcoef(img[..., ch].ravel(), ref[..., ch].ravel())[0, 1] > 0.985
     assert np.percentile(diff, 99) < 0.08
+
+
+@pytest.mark.parametrize("name", ["spot", "lens", "sphere_floor", "ogre"])
+def test_oracle_reproduces_committed_renders(oracle, name):
+    """The committed render vectors (tests/golden/render_*.npz, made by make_golden.py) are what
+    the GPU path is held to; the oracle must keep producing exactly them."""
+    import raytracer_amd as rt
+
+    g = np.load(os.path.join(HERE, "golden", f"render_{name}.npz"))
+    w, h, spp, seed = (int(x) for x in g["params"])
+    c = np.zeros((h, w, 3))
+    rays, _ = oracle.OracleScene.build(name).render(c, rt.render_params(width=w, height=h, spp=spp, seed=seed))
+    assert rays == int(g["rays"])
+    assert c.tobytes() == g["canvas"].tobytes()

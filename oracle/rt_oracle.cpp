@@ -90,7 +90,7 @@ Mat3H rot_z(double theta) {
   double c = std::cos(theta), s = std::sin(theta);
   return Mat3H{{{c, s, 0.0, 0.0}, {-s, c, 0.0, 0.0}, {0.0, 0.0, 1.0, 0.0}, {0.0, 0.0, 0.0, 1.0}}};
 }
-Mat3H rot_x(double theta) {
+[[maybe_unused]] Mat3H rot_x(double theta) {
   double c = std::cos(theta), s = std::sin(theta);
   return Mat3H{{{1.0, 0.0, 0.0, 0.0}, {0.0, c, -s, 0.0}, {0.0, s, c, 0.0}, {0.0, 0.0, 0.0, 1.0}}};
 }

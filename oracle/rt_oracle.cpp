@@ -1177,7 +1177,20 @@ void bvh_trace(const uint32_t* node_words, uint32_t n_nodes, int32_t root_ref, c
     float o32 = (float)origin.c[k];
     double d = dir.c[k];
     if (std::fabs(d) < 1e-30) d = std::signbit(d) ? -1e-30 : 1e-30;
-    inv[k] = (float)(1.0 / d);
+    // The kernel takes the hardware's binary32 reciprocal of the rounded component (v_rcp_f32,
+    // within one unit in the last place of the exact reciprocal). Restated here as the correctly
+    // rounded reciprocal pushed one unit up or down, or left alone, as a hash of the ray decides:
+    // the margins of the culling test must hold for every such error.
+    inv[k] = 1.0f / (float)d;
+    {
+      uint64_t bits;
+      std::memcpy(&bits, &dir.c[k], 8);
+      uint64_t obits;
+      std::memcpy(&obits, &origin.c[(k + 1) % 3], 8);
+      const uint64_t hsh = mix64(bits ^ (obits * 0x9e3779b97f4a7c15ull) ^ (uint64_t)k);
+      if ((hsh & 3u) == 1u) inv[k] = std::nextafter(inv[k], INFINITY);
+      if ((hsh & 3u) == 2u) inv[k] = std::nextafter(inv[k], -INFINITY);
+    }
     m_lo[k] = -(o32 - pad) * inv[k];
     m_hi[k] = -(o32 + pad) * inv[k];
   }

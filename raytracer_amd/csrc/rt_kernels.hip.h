@@ -170,6 +170,16 @@ __device__ __forceinline__ float f32_up(double x) {
   return __double2float_ru(x);
 }
 
+// Two binary32 values in a register pair, for the packed operations of the slab tests.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 mk2(float a, float b) {
+  f2 r;
+  r.x = a;
+  r.y = b;
+  return r;
+}
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
 // Per-lane traversal state, resumable: a lane can stop after a bounded number of steps and any
 // lane of the block can pick the ray up later (the stack lives in LDS and is addressed by the
 // column index of the lane that started the ray).
@@ -196,9 +206,12 @@ __device__ __forceinline__ void trav_set_ray(Trav& t, const d3 o, const d3 d) {
   if (fabs(dx) < 1e-30) dx = signbit(dx) ? -1e-30 : 1e-30;
   if (fabs(dy) < 1e-30) dy = signbit(dy) ? -1e-30 : 1e-30;
   if (fabs(dz) < 1e-30) dz = signbit(dz) ? -1e-30 : 1e-30;
-  t.ix = (float)(1.0 / dx);
-  t.iy = (float)(1.0 / dy);
-  t.iz = (float)(1.0 / dz);
+  // v_rcp_f32 of the rounded component: within 1.5 * 2^-23 of 1/d, which the far-plane factor
+  // covers twice over ((1+e)/(1-e) with e = 1.5 * 2^-23 plus the fused operations' 2^-24 each is
+  // 1 + 4.8e-7; the factor is 1 + 9.5e-7). Three binary64 divisions per ray cost ten times more.
+  t.ix = __builtin_amdgcn_rcpf((float)dx);
+  t.iy = __builtin_amdgcn_rcpf((float)dy);
+  t.iz = __builtin_amdgcn_rcpf((float)dz);
   // for a box's min plane use o + pad, for its max plane o - pad (pads the box, whatever the sign)
   t.mx_lo = -(ox - pad) * t.ix;
   t.mx_hi = -(ox + pad) * t.ix;
@@ -254,33 +267,27 @@ __device__ __forceinline__ void trav_run(Trav& t, const SceneK& sc, const int st
       }
       // A NaN plane distance (inf - inf when a direction component is zero and the numbers are
       // huge) drops out of fminf/fmaxf, which then ignore that plane: still conservative.
-      float ta, tb, tn0, tf0, tn1, tf1;
+      // Both planes of an axis in one packed operation (v_pk_fma_f32): {min, max} * inv + {m_hi, m_lo}.
+      const f2 x0 = pk_fma(mk2(bx.x, bx.y), mk2(ix, ix), mk2(mx_hi, mx_lo));
+      const f2 y0 = pk_fma(mk2(by.x, by.y), mk2(iy, iy), mk2(my_hi, my_lo));
+      const f2 z0 = pk_fma(mk2(bz.x, bz.y), mk2(iz, iz), mk2(mz_hi, mz_lo));
+      const f2 x1 = pk_fma(mk2(bx.z, bx.w), mk2(ix, ix), mk2(mx_hi, mx_lo));
+      const f2 y1 = pk_fma(mk2(by.z, by.w), mk2(iy, iy), mk2(my_hi, my_lo));
+      const f2 z1 = pk_fma(mk2(bz.z, bz.w), mk2(iz, iz), mk2(mz_hi, mz_lo));
+      float tn0, tf0, tn1, tf1;
       // child 0
-      ta = __builtin_fmaf(bx.x, ix, mx_hi);
-      tb = __builtin_fmaf(bx.y, ix, mx_lo);
-      tn0 = fminf(ta, tb);
-      tf0 = fmaxf(ta, tb);
-      ta = __builtin_fmaf(by.x, iy, my_hi);
-      tb = __builtin_fmaf(by.y, iy, my_lo);
-      tn0 = fmaxf(tn0, fminf(ta, tb));
-      tf0 = fminf(tf0, fmaxf(ta, tb));
-      ta = __builtin_fmaf(bz.x, iz, mz_hi);
-      tb = __builtin_fmaf(bz.y, iz, mz_lo);
-      tn0 = fmaxf(fmaxf(tn0, fminf(ta, tb)), 0.0f);
-      tf0 = fminf(tf0, fmaxf(ta, tb)) * RT_K_FAR;
+      tn0 = fmaxf(fminf(x0.x, x0.y), fminf(y0.x, y0.y));
+      tf0 = fminf(fmaxf(x0.x, x0.y), fmaxf(y0.x, y0.y));
+      tn0 = fmaxf(fmaxf(tn0, fminf(z0.x, z0.y)), 0.0f);
+      tf0 = fminf(tf0, fmaxf(z0.x, z0.y));
       // child 1
-      ta = __builtin_fmaf(bx.z, ix, mx_hi);
-      tb = __builtin_fmaf(bx.w, ix, mx_lo);
-      tn1 = fminf(ta, tb);
-      tf1 = fmaxf(ta, tb);
-      ta = __builtin_fmaf(by.z, iy, my_hi);
-      tb = __builtin_fmaf(by.w, iy, my_lo);
-      tn1 = fmaxf(tn1, fminf(ta, tb));
-      tf1 = fminf(tf1, fmaxf(ta, tb));
-      ta = __builtin_fmaf(bz.z, iz, mz_hi);
-      tb = __builtin_fmaf(bz.w, iz, mz_lo);
-      tn1 = fmaxf(fmaxf(tn1, fminf(ta, tb)), 0.0f);
-      tf1 = fminf(tf1, fmaxf(ta, tb)) * RT_K_FAR;
+      tn1 = fmaxf(fminf(x1.x, x1.y), fminf(y1.x, y1.y));
+      tf1 = fminf(fmaxf(x1.x, x1.y), fmaxf(y1.x, y1.y));
+      tn1 = fmaxf(fmaxf(tn1, fminf(z1.x, z1.y)), 0.0f);
+      tf1 = fminf(tf1, fmaxf(z1.x, z1.y));
+      const f2 tf = mk2(tf0, tf1) * mk2(RT_K_FAR, RT_K_FAR);
+      tf0 = tf.x;
+      tf1 = tf.y;
 
       const bool h0 = tn0 <= fminf(tf0, best32k);
       const bool h1 = tn1 <= fminf(tf1, best32k);

@@ -311,7 +311,7 @@ __device__ __forceinline__ void trav_run(Trav& t, const SceneK& sc, const int st
     if (paused || cur == RT_REF_SENTINEL) break;
     // leaf
     const uint32_t leaf = (uint32_t)~cur;
-    const uint32_t first = leaf >> 2, cnt = (leaf & 3u) + 1u;
+    const uint32_t first = leaf >> RT_LEAF_BITS, cnt = (leaf & (uint32_t)(RT_LEAF_MAX - 1)) + 1u;
     for (uint32_t i = 0; i < cnt; ++i) {
       if (COUNT && first_active_lane()) wc.wi_leaf++;
       const TriGeom* g = sc.geom + (first + i);

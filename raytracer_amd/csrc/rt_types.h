@@ -18,13 +18,16 @@
 
 #include "../../include/rt_amd.h"
 
-#define RT_LEAF_MAX 4                 /* triangles per leaf                                  */
+#ifndef RT_LEAF_BITS
+#define RT_LEAF_BITS 2                /* a leaf ref keeps (count - 1) in this many low bits    */
+#endif
+#define RT_LEAF_MAX (1 << RT_LEAF_BITS) /* triangles per leaf                                 */
 #define RT_BVH_MAX_DEPTH 62           /* builder guarantee; the traversal stack is sized by it */
 #define RT_REF_SENTINEL INT32_MIN     /* bottom of the traversal stack / empty tree          */
 #define RT_REJECT_CAP 64              /* tries per rejection loop before the fallback        */
 
 // A child ref >= 0 is the index of an interior node. A ref < 0 other than RT_REF_SENTINEL is a
-// leaf: ~ref = first_slot * 4 + (count - 1).
+// leaf: ~ref = first_slot * RT_LEAF_MAX + (count - 1).
 struct alignas(16) BvhNode {
   float bx[4];  // child0.min.x child0.max.x child1.min.x child1.max.x
   float by[4];

@@ -1181,7 +1181,7 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
     if (mega) {
       uint32_t grid = blocks_all;
       if (regen) {
-        grid = std::min<uint32_t>(blocks_all, (uint32_t)cus * 8u);
+        grid = std::min<uint32_t>(blocks_all, (uint32_t)cus * 8u * (256u / RT_BLOCK));  // 32 waves per CU
         HIP_TRY(hipMemsetAsync(d->counters + CNT_WORK, 0, sizeof(unsigned long long), stream));
       }
       if ((rc = begin_launch(3, pp.n_paths, stream)) != RT_OK) return rc;

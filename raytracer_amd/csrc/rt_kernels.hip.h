@@ -21,7 +21,9 @@
 #include "rt_types.h"
 
 #define RT_WAVE 64
-#define RT_BLOCK 256
+#ifndef RT_BLOCK
+#define RT_BLOCK 64
+#endif
 
 namespace rtk {
 

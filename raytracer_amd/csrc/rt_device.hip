@@ -1047,7 +1047,16 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
   // Work buffers are bounded (RT_WORK_BUFFER_MIB); a call that needs more runs in sample chunks.
   const uint64_t n_pix = (uint64_t)tm.n_tiles * 64u;
   const size_t per_path = 24u + (mega ? 0u : 2u * (sizeof(QueueRec) + (emission ? 24u : 0u)));
-  const size_t budget = env_mib("RT_WORK_BUFFER_MIB", 65536) << 20;
+  // Budget of the work buffers: RT_WORK_BUFFER_MIB, else 192 GiB of the MI355X's 288 GB, and in
+  // any case no more than four fifths of what is free (counting what the scene already holds).
+  size_t budget = env_mib("RT_WORK_BUFFER_MIB", 196608) << 20;
+  {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      const size_t held = d->samples_bytes + d->totals_bytes + d->queue_bytes[0] + d->queue_bytes[1] + d->queue_rad_bytes[0] + d->queue_rad_bytes[1];
+      budget = std::min<size_t>(budget, (free_b + held) / 5 * 4);
+    }
+  }
   uint64_t chunk64 = std::max<uint64_t>(1, budget / (n_pix * per_path));
   chunk64 = std::min<uint64_t>(chunk64, 0xfff00000ull / n_pix);
   if (chunk64 == 0) {

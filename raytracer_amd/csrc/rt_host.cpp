@@ -332,6 +332,42 @@ extern "C" int rt_objects_push_sphere(rt_objects* objs, const double centre[3], 
   return (int)objs->items.size() - 1;
 }
 
+// Triangle records in leaf order (rt_types.h), from the flat arrays and s->leaf_order.
+void rt_fill_leaf_records(rt_scene* s) {
+  const size_t n = s->leaf_order.size();
+  s->tri_geom.resize(n);
+  s->tri_shade.resize(n);
+  for (size_t slot = 0; slot < n; ++slot) {
+    const size_t t = (size_t)s->leaf_order[slot];
+    TriGeom& g = s->tri_geom[slot];
+    const double* v = &s->tri_vertices[t * 9];
+    for (int c = 0; c < 3; ++c) {
+      g.a[c] = v[c];
+      g.ab[c] = v[3 + c] - v[c];  // src/main.rs:188
+      g.ac[c] = v[6 + c] - v[c];  // src/main.rs:189
+    }
+    g.flat = (int32_t)t;
+    g.obj = s->tri_obj[t];
+    TriShade& sh = s->tri_shade[slot];
+    for (int k = 0; k < 3; ++k) {
+      for (int c = 0; c < 3; ++c) sh.n[k][c] = s->tri_normals[t * 9 + k * 3 + c];
+      for (int c = 0; c < 2; ++c) sh.uv[k][c] = s->tri_uvs[t * 6 + k * 2 + c];
+    }
+    sh.tri = s->tri_idx[t];
+    sh.obj = s->tri_obj[t];
+  }
+}
+
+// Absolute padding of every child box: 2^-20 of the largest finite coordinate in the scene (at
+// least 2^-20). It covers the rounding slop of the binary64 triangle test (a hit accepted a hair
+// outside the exact triangle) with five orders of magnitude to spare for well-conditioned hits.
+double rt_scene_box_pad(const rt_scene* s) {
+  double extent = 1.0;
+  for (double x : s->tri_vertices)
+    if (std::isfinite(x)) extent = std::max(extent, std::fabs(x));
+  return extent * 9.5367431640625e-07;
+}
+
 // ------------------------------------------------------------------------------------------
 // acceleration structure
 // ------------------------------------------------------------------------------------------
@@ -577,7 +613,6 @@ int build_scene_accel(rt_scene* s) {
   };
   std::vector<Box> tb(n);
   std::vector<double> cen(n * 3);
-  double extent = 1.0;
   for (size_t t = 0; t < n; ++t) {
     Box b = box_empty();
     for (int k = 0; k < 3; ++k)
@@ -585,17 +620,13 @@ int build_scene_accel(rt_scene* s) {
         double x = s->tri_vertices[t * 9 + k * 3 + c];
         b.lo[c] = std::min(b.lo[c], x);
         b.hi[c] = std::max(b.hi[c], x);
-        if (std::isfinite(x)) extent = std::max(extent, std::fabs(x));
       }
     tb[t] = b;
     for (int c = 0; c < 3; ++c) cen[t * 3 + c] = 0.5 * b.lo[c] + 0.5 * b.hi[c];
   }
   s->leaf_order.resize(n);
   for (size_t i = 0; i < n; ++i) s->leaf_order[i] = (int32_t)i;
-  // Absolute padding of every child box: 2^-20 of the largest coordinate in the scene. It
-  // covers the rounding slop of the binary64 triangle test (a hit accepted a hair outside
-  // the exact triangle) with five orders of magnitude to spare for well-conditioned hits.
-  const double pad = extent * 9.5367431640625e-07;
+  const double pad = rt_scene_box_pad(s);
   std::vector<int32_t> scratch(n);
   Builder b{tb, cen, s->leaf_order, scratch, pad};
   int fork_levels = 0;  // 2^fork_levels subtree builds run at once; RT_BUILD_THREADS caps it
@@ -617,27 +648,7 @@ int build_scene_accel(rt_scene* s) {
   // left subtree (the same for any thread count, since a forked subtree is spliced in where the
   // sequential build would have put it). Measured against a breadth-first renumbering this is
   // up to 5 % faster to traverse: the near part of a walk down the tree shares cache lines.
-  s->tri_geom.resize(n);
-  s->tri_shade.resize(n);
-  for (size_t slot = 0; slot < n; ++slot) {
-    const size_t t = (size_t)s->leaf_order[slot];
-    TriGeom& g = s->tri_geom[slot];
-    const double* v = &s->tri_vertices[t * 9];
-    for (int c = 0; c < 3; ++c) {
-      g.a[c] = v[c];
-      g.ab[c] = v[3 + c] - v[c];  // src/main.rs:188
-      g.ac[c] = v[6 + c] - v[c];  // src/main.rs:189
-    }
-    g.flat = (int32_t)t;
-    g.obj = s->tri_obj[t];
-    TriShade& sh = s->tri_shade[slot];
-    for (int k = 0; k < 3; ++k) {
-      for (int c = 0; c < 3; ++c) sh.n[k][c] = s->tri_normals[t * 9 + k * 3 + c];
-      for (int c = 0; c < 2; ++c) sh.uv[k][c] = s->tri_uvs[t * 6 + k * 2 + c];
-    }
-    sh.tri = s->tri_idx[t];
-    sh.obj = s->tri_obj[t];
-  }
+  rt_fill_leaf_records(s);
   lap("records");
   return RT_OK;
 }

@@ -102,6 +102,8 @@ struct rt_scene {
 
 // rt_host.cpp
 void rt_set_error(const char* fmt, ...);
+void rt_fill_leaf_records(rt_scene* s);
+double rt_scene_box_pad(const rt_scene* s);
 // rt_device.hip
 void rt_device_scene_free(DeviceScene* d);
 int rt_device_scene_info(const DeviceScene* d, uint32_t* device_plus_one, uint64_t* bytes);

@@ -190,6 +190,7 @@ extern "C" {
 
     pub fn rt_device_count() -> c_int;
     pub fn rt_scene_upload(scene: *mut rt_scene, device: c_int) -> c_int;
+    pub fn rt_scene_rebuild_on_device(scene: *mut rt_scene, device: c_int) -> c_int;
     pub fn rt_trace(scene: *mut rt_scene, org3: *const f64, dir3: *const f64, n: usize, out: *mut rt_hit) -> c_int;
     pub fn rt_primary_hits(scene: *mut rt_scene, p: *const rt_render_params, obj: *mut i32, tri: *mut i32, t: *mut f64, u: *mut f64, v: *mut f64) -> c_int;
     pub fn rt_render_accumulate(scene: *mut rt_scene, p: *const rt_render_params, canvas: *mut f64, rays_out: *mut u64) -> c_int;

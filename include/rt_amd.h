@@ -270,6 +270,15 @@ int rt_device_count(void);
 /* Copies the scene into the HBM of `device` (idempotent for the same device). */
 int rt_scene_upload(rt_scene* scene, int device);
 
+/* Replaces the scene's tree (built on the host when the scene was created; BVH::build,
+ * src/main.rs:771) by a linear BVH built on `device`: Morton codes, one radix sort, the
+ * hierarchy and its boxes in a few kernels. Milliseconds instead of tenths of a second for a
+ * million triangles, at the price of slower traversal: for scenes that change from frame to
+ * frame. Hit records do not depend on the tree. The scene must be uploaded again afterwards
+ * (the render calls do that themselves). RT_ERR_INVALID, with the host tree kept, if the linear
+ * tree would be deeper than the traversal stack allows (62 levels). */
+int rt_scene_rebuild_on_device(rt_scene* scene, int device);
+
 /* Batch Scene::hit, src/main.rs:776-814. org3/dir3 are [n][3]; dir need not be unit length. */
 int rt_trace(rt_scene* scene, const double* org3, const double* dir3, size_t n, rt_hit* out);
 

@@ -174,6 +174,7 @@ SIGNATURES = {
     "rt_scene_export_texture": (C.c_int, [_P, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _P]),
     "rt_scene_export_bvh": (C.c_int, [_P, _P, _P]),
     "rt_device_count": (C.c_int, []),
+    "rt_scene_rebuild_on_device": (C.c_int, [_P, C.c_int]),
     "rt_scene_upload": (C.c_int, [_P, C.c_int]),
     "rt_trace": (C.c_int, [_P, _P, _P, C.c_size_t, _P]),
     "rt_primary_hits": (C.c_int, [_P, C.POINTER(rt_render_params), _P, _P, _P, _P, _P]),

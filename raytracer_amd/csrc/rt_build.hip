@@ -1,0 +1,351 @@
+// rt_build.hip — the acceleration structure built on the GPU.
+//
+// The reference builds its tree on the CPU (BVH::build of crate bvh 0.6.0, src/main.rs:771) once
+// per scene. rt_scene_rebuild_on_device replaces the host-built tree of a scene by a linear BVH
+// made on the device: Morton codes of the triangle centroids, one radix sort, the hierarchy of
+// Karras ("Maximizing parallelism in the construction of BVHs, octrees and k-d trees", 2012), a
+// bottom-up pass for the boxes, and a last pass that writes nodes in the library's own format
+// (rt_types.h: two child boxes per 64-byte node, leaves of 1..RT_LEAF_MAX triangles). A linear
+// BVH takes milliseconds where the host's binned-SAH builder takes tenths of a second, and
+// traverses slower; it is for scenes that change between frames, not the default.
+//
+// The nearest hit does not depend on the tree (every box contains its triangles: exact binary64
+// minima and maxima, rounded outward to binary32 and padded exactly as the host builder does),
+// so hit records stay bit-identical to the host-built tree's.
+
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#include "rt_types.h"
+
+namespace {
+
+#define BUILD_BLOCK 256
+
+#define HIP_TRY_B(expr)                                                                        \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      rt_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return RT_ERR_HIP;                                                                       \
+    }                                                                                          \
+  } while (0)
+
+struct Box6 {
+  double lo[3], hi[3];
+};
+
+// 21 bits -> every third bit of a 63-bit word
+__device__ __forceinline__ uint64_t spread21(uint64_t v) {
+  v &= 0x1fffffull;
+  v = (v | (v << 32)) & 0x1f00000000ffffull;
+  v = (v | (v << 16)) & 0x1f0000ff0000ffull;
+  v = (v | (v << 8)) & 0x100f00f00f00f00full;
+  v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+  v = (v | (v << 2)) & 0x1249249249249249ull;
+  return v;
+}
+
+// Per triangle: its binary64 box and the Morton code of the box centre within `clo..chi`.
+__global__ void k_boxes_codes(const double* __restrict__ verts, uint32_t n, double clo_x, double clo_y, double clo_z, double sx,
+                              double sy, double sz, Box6* __restrict__ boxes, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const double* v = verts + (size_t)t * 9;
+  Box6 b;
+  for (int c = 0; c < 3; ++c) {
+    b.lo[c] = fmin(v[c], fmin(v[3 + c], v[6 + c]));
+    b.hi[c] = fmax(v[c], fmax(v[3 + c], v[6 + c]));
+  }
+  boxes[t] = b;
+  const double clo[3] = {clo_x, clo_y, clo_z}, sc[3] = {sx, sy, sz};
+  uint64_t q[3];
+  for (int c = 0; c < 3; ++c) {
+    double f = (0.5 * b.lo[c] + 0.5 * b.hi[c] - clo[c]) * sc[c];  // 0 .. 2^21, NaN for non-finite data
+    f = fmin(fmax(f, 0.0), 2097151.0);                            // fmax(NaN, 0) = 0
+    q[c] = (uint64_t)f;
+  }
+  keys[t] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
+  vals[t] = t;
+}
+
+// Length of the common prefix of the keys at sorted positions i and j; equal keys are told apart
+// by their positions, so that every pair of leaves differs. -1 outside the array.
+__device__ __forceinline__ int delta(const uint64_t* __restrict__ keys, int n, int i, int j) {
+  if (j < 0 || j >= n) return -1;
+  const uint64_t a = keys[i], b = keys[j];
+  if (a == b) return 64 + __clz((unsigned)(i ^ j));
+  return __clzll((long long)(a ^ b));
+}
+
+// Child references of the hierarchy: >= 0 internal node, < 0 leaf ~position.
+// One thread per internal node (n - 1 of them): its range of sorted positions and its children.
+__global__ void k_hierarchy(const uint64_t* __restrict__ keys, int n, int2* __restrict__ child, int2* __restrict__ range,
+                            int* __restrict__ parent_node, int* __restrict__ parent_leaf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n - 1) return;
+  const int d = delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1) >= 0 ? 1 : -1;
+  const int dmin = delta(keys, n, i, i - d);
+  int lmax = 2;
+  while (delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+  int l = 0;
+  for (int t = lmax / 2; t >= 1; t /= 2)
+    if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+  const int j = i + l * d;
+  const int dnode = delta(keys, n, i, j);
+  int s = 0;
+  int t = l;
+  do {
+    t = (t + 1) >> 1;
+    if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+  } while (t > 1);
+  const int gamma = i + s * d + (d < 0 ? -1 : 0);
+  const int first = min(i, j), last = max(i, j);
+  const int left = first == gamma ? ~gamma : gamma;
+  const int right = last == gamma + 1 ? ~(gamma + 1) : gamma + 1;
+  child[i] = make_int2(left, right);
+  range[i] = make_int2(first, last);
+  if (left >= 0) parent_node[left] = i;
+  else parent_leaf[~left] = i;
+  if (right >= 0) parent_node[right] = i;
+  else parent_leaf[~right] = i;
+  if (i == 0) parent_node[0] = -1;
+}
+
+__device__ __forceinline__ Box6 box_union(const Box6& a, const Box6& b) {
+  Box6 r;
+  for (int c = 0; c < 3; ++c) {
+    r.lo[c] = fmin(a.lo[c], b.lo[c]);
+    r.hi[c] = fmax(a.hi[c], b.hi[c]);
+  }
+  return r;
+}
+
+// One thread per leaf walks towards the root; the second thread to reach a node computes its box.
+__global__ void k_fit(int n, const int2* __restrict__ child, const int* __restrict__ parent_node, const int* __restrict__ parent_leaf,
+                      const uint32_t* __restrict__ vals, const Box6* __restrict__ tri_boxes, Box6* node_boxes, int* visits) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  int node = parent_leaf[p];
+  while (node >= 0) {
+    __threadfence();
+    if (atomicAdd(&visits[node], 1) == 0) return;  // the sibling subtree is not done yet
+    __threadfence();
+    const int2 ch = child[node];
+    const Box6 a = ch.x >= 0 ? node_boxes[ch.x] : tri_boxes[vals[~ch.x]];
+    const Box6 b = ch.y >= 0 ? node_boxes[ch.y] : tri_boxes[vals[~ch.y]];
+    node_boxes[node] = box_union(a, b);
+    node = parent_node[node];
+  }
+}
+
+// Nodes that cover more than RT_LEAF_MAX triangles are kept; smaller subtrees become leaves.
+__global__ void k_mark(int n, const int2* __restrict__ range, uint32_t* __restrict__ kept) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n - 1) return;
+  kept[i] = (range[i].y - range[i].x + 1) > RT_LEAF_MAX ? 1u : 0u;
+}
+
+__global__ void k_emit(int n, const int2* __restrict__ child, const int2* __restrict__ range, const int* __restrict__ parent_node,
+                       const uint32_t* __restrict__ kept, const uint32_t* __restrict__ slot_of, const uint32_t* __restrict__ vals,
+                       const Box6* __restrict__ tri_boxes, const Box6* __restrict__ node_boxes, double pad, BvhNode* __restrict__ out,
+                       unsigned int* __restrict__ stats /* [0] leaves, [1] deepest leaf */) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n - 1 || !kept[i]) return;
+  BvhNode nd = {};
+  const int2 ch = child[i];
+  unsigned int leaves = 0;
+  for (int c = 0; c < 2; ++c) {
+    const int r = c ? ch.y : ch.x;
+    Box6 b;
+    int32_t ref;
+    if (r < 0) {  // a single triangle
+      b = tri_boxes[vals[~r]];
+      ref = ~(int32_t)((uint32_t)(~r) * RT_LEAF_MAX + 0u);
+      leaves++;
+    } else {
+      b = node_boxes[r];
+      if (kept[r]) {
+        ref = (int32_t)slot_of[r];
+      } else {
+        const int2 rg = range[r];
+        ref = ~(int32_t)((uint32_t)rg.x * RT_LEAF_MAX + (uint32_t)(rg.y - rg.x));
+        leaves++;
+      }
+    }
+    nd.bx[c * 2 + 0] = __double2float_rd(b.lo[0] - pad);
+    nd.bx[c * 2 + 1] = __double2float_ru(b.hi[0] + pad);
+    nd.by[c * 2 + 0] = __double2float_rd(b.lo[1] - pad);
+    nd.by[c * 2 + 1] = __double2float_ru(b.hi[1] + pad);
+    nd.bz[c * 2 + 0] = __double2float_rd(b.lo[2] - pad);
+    nd.bz[c * 2 + 1] = __double2float_ru(b.hi[2] + pad);
+    nd.child[c] = ref;
+  }
+  out[slot_of[i]] = nd;
+  if (leaves) {
+    unsigned int depth = 1;  // interior nodes above a leaf of this node: the node and its ancestors
+    for (int a = parent_node[i]; a >= 0; a = parent_node[a]) depth++;
+    atomicAdd(&stats[0], leaves);
+    atomicMax(&stats[1], depth);
+  }
+}
+
+struct DevMem {  // frees what a failed or finished build allocated
+  std::vector<void*> ptrs;
+  ~DevMem() {
+    for (void* p : ptrs) (void)hipFree(p);
+  }
+  template <typename T>
+  int get(T** out, size_t count) {
+    void* p = nullptr;
+    if (hipMalloc(&p, std::max<size_t>(1, count) * sizeof(T)) != hipSuccess) {
+      rt_set_error("rt_scene_rebuild_on_device: out of device memory");
+      return RT_ERR_OOM;
+    }
+    ptrs.push_back(p);
+    *out = static_cast<T*>(p);
+    return RT_OK;
+  }
+};
+
+}  // namespace
+
+extern "C" int rt_scene_rebuild_on_device(rt_scene* s, int device) {
+  if (!s) {
+    rt_set_error("rt_scene_rebuild_on_device: null scene");
+    return RT_ERR_INVALID;
+  }
+  const int n_dev = rt_device_count();
+  if (n_dev <= 0) {
+    rt_set_error("rt_scene_rebuild_on_device: no HIP device is visible; this library has no CPU path");
+    return RT_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= n_dev) {
+    rt_set_error("rt_scene_rebuild_on_device: device %d out of range (0..%d)", device, n_dev - 1);
+    return RT_ERR_INVALID;
+  }
+  const size_t n = s->tri_obj.size();
+  if (n == 0) return RT_OK;  // spheres only: there is no tree
+  HIP_TRY_B(hipSetDevice(device));
+
+  // centre bounds of the triangle boxes, for the quantisation of the Morton codes
+  double clo[3], chi[3];
+  for (int c = 0; c < 3; ++c) {
+    clo[c] = std::numeric_limits<double>::infinity();
+    chi[c] = -std::numeric_limits<double>::infinity();
+  }
+  for (size_t t = 0; t < n; ++t) {
+    const double* v = &s->tri_vertices[t * 9];
+    for (int c = 0; c < 3; ++c) {
+      const double lo = std::min(v[c], std::min(v[3 + c], v[6 + c])), hi = std::max(v[c], std::max(v[3 + c], v[6 + c]));
+      const double m = 0.5 * lo + 0.5 * hi;
+      if (std::isfinite(m)) {
+        clo[c] = std::min(clo[c], m);
+        chi[c] = std::max(chi[c], m);
+      }
+    }
+  }
+  double scale[3];
+  for (int c = 0; c < 3; ++c) {
+    if (!(chi[c] >= clo[c])) clo[c] = chi[c] = 0.0;
+    const double ext = chi[c] - clo[c];
+    scale[c] = ext > 0.0 && std::isfinite(ext) ? 2097152.0 / ext : 0.0;
+  }
+  const double pad = rt_scene_box_pad(s);
+
+  DevMem mem;
+  int rc;
+  double* d_verts;
+  Box6 *d_tri_boxes, *d_node_boxes;
+  uint64_t *d_keys, *d_keys_sorted;
+  uint32_t *d_vals, *d_vals_sorted, *d_kept, *d_slot;
+  int2 *d_child, *d_range;
+  int *d_parent_node, *d_parent_leaf, *d_visits;
+  unsigned int* d_stats;
+  BvhNode* d_nodes;
+  const size_t ni = n - 1;  // internal nodes of the hierarchy
+  if ((rc = mem.get(&d_verts, n * 9)) || (rc = mem.get(&d_tri_boxes, n)) || (rc = mem.get(&d_node_boxes, ni)) ||
+      (rc = mem.get(&d_keys, n)) || (rc = mem.get(&d_keys_sorted, n)) || (rc = mem.get(&d_vals, n)) ||
+      (rc = mem.get(&d_vals_sorted, n)) || (rc = mem.get(&d_kept, ni + 1)) || (rc = mem.get(&d_slot, ni + 1)) ||
+      (rc = mem.get(&d_child, ni)) || (rc = mem.get(&d_range, ni)) || (rc = mem.get(&d_parent_node, ni + 1)) ||
+      (rc = mem.get(&d_parent_leaf, n)) || (rc = mem.get(&d_visits, ni + 1)) || (rc = mem.get(&d_stats, 2)) ||
+      (rc = mem.get(&d_nodes, ni)))
+    return rc;
+  HIP_TRY_B(hipMemcpy(d_verts, s->tri_vertices.data(), n * 9 * sizeof(double), hipMemcpyHostToDevice));
+  const uint32_t grid_n = (uint32_t)((n + BUILD_BLOCK - 1) / BUILD_BLOCK);
+  hipLaunchKernelGGL(k_boxes_codes, dim3(grid_n), dim3(BUILD_BLOCK), 0, nullptr, d_verts, (uint32_t)n, clo[0], clo[1], clo[2], scale[0],
+                     scale[1], scale[2], d_tri_boxes, d_keys, d_vals);
+  HIP_TRY_B(hipGetLastError());
+
+  // sort positions by code (stable, so equal codes stay in flat order)
+  size_t tmp_bytes = 0;
+  HIP_TRY_B(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_keys, d_keys_sorted, d_vals, d_vals_sorted, (int)n, 0, 63, nullptr));
+  char* d_tmp;
+  if ((rc = mem.get(&d_tmp, tmp_bytes))) return rc;
+  HIP_TRY_B(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_keys, d_keys_sorted, d_vals, d_vals_sorted, (int)n, 0, 63, nullptr));
+
+  std::vector<int32_t> leaf_order(n);
+  std::vector<BvhNode> nodes;
+  int32_t root_ref;
+  uint32_t depth = 0, leaves = 1;
+  if (n <= (size_t)RT_LEAF_MAX) {
+    root_ref = ~(int32_t)(0u * RT_LEAF_MAX + (uint32_t)(n - 1));  // the whole scene is one leaf
+  } else {
+    const uint32_t grid_i = (uint32_t)((ni + BUILD_BLOCK - 1) / BUILD_BLOCK);
+    hipLaunchKernelGGL(k_hierarchy, dim3(grid_i), dim3(BUILD_BLOCK), 0, nullptr, d_keys_sorted, (int)n, d_child, d_range, d_parent_node,
+                       d_parent_leaf);
+    HIP_TRY_B(hipGetLastError());
+    HIP_TRY_B(hipMemsetAsync(d_visits, 0, (ni + 1) * sizeof(int), nullptr));
+    hipLaunchKernelGGL(k_fit, dim3(grid_n), dim3(BUILD_BLOCK), 0, nullptr, (int)n, d_child, d_parent_node, d_parent_leaf, d_vals_sorted,
+                       d_tri_boxes, d_node_boxes, d_visits);
+    HIP_TRY_B(hipGetLastError());
+    hipLaunchKernelGGL(k_mark, dim3(grid_i), dim3(BUILD_BLOCK), 0, nullptr, (int)n, d_range, d_kept);
+    HIP_TRY_B(hipGetLastError());
+    size_t scan_bytes = 0;
+    HIP_TRY_B(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_kept, d_slot, (int)ni, nullptr));
+    char* d_scan;
+    if ((rc = mem.get(&d_scan, scan_bytes))) return rc;
+    HIP_TRY_B(hipcub::DeviceScan::ExclusiveSum(d_scan, scan_bytes, d_kept, d_slot, (int)ni, nullptr));
+    HIP_TRY_B(hipMemsetAsync(d_stats, 0, 2 * sizeof(unsigned int), nullptr));
+    hipLaunchKernelGGL(k_emit, dim3(grid_i), dim3(BUILD_BLOCK), 0, nullptr, (int)n, d_child, d_range, d_parent_node, d_kept, d_slot,
+                       d_vals_sorted, d_tri_boxes, d_node_boxes, pad, d_nodes, d_stats);
+    HIP_TRY_B(hipGetLastError());
+    uint32_t last_kept = 0, last_slot = 0;
+    unsigned int stats[2] = {0, 0};
+    HIP_TRY_B(hipMemcpy(&last_kept, d_kept + (ni - 1), sizeof last_kept, hipMemcpyDeviceToHost));
+    HIP_TRY_B(hipMemcpy(&last_slot, d_slot + (ni - 1), sizeof last_slot, hipMemcpyDeviceToHost));
+    HIP_TRY_B(hipMemcpy(stats, d_stats, sizeof stats, hipMemcpyDeviceToHost));
+    const size_t n_nodes = (size_t)last_slot + last_kept;
+    if (stats[1] > RT_BVH_MAX_DEPTH) {
+      rt_set_error("rt_scene_rebuild_on_device: the linear tree is %u levels deep (limit %d); the scene keeps its host-built tree",
+                   stats[1], RT_BVH_MAX_DEPTH);
+      return RT_ERR_INVALID;
+    }
+    nodes.resize(n_nodes);
+    HIP_TRY_B(hipMemcpy(nodes.data(), d_nodes, n_nodes * sizeof(BvhNode), hipMemcpyDeviceToHost));
+    root_ref = 0;  // node 0 of the hierarchy is the root, covers everything, and is kept: slot 0
+    depth = stats[1];
+    leaves = stats[0];
+  }
+  HIP_TRY_B(hipMemcpy(leaf_order.data(), d_vals_sorted, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+
+  // the scene takes the new tree; its device copy, if any, is stale
+  if (s->dev) {
+    rt_device_scene_free(s->dev);
+    s->dev = nullptr;
+  }
+  s->nodes.swap(nodes);
+  s->leaf_order.swap(leaf_order);
+  s->root_ref = root_ref;
+  s->bvh_depth = depth;
+  s->bvh_leaves = leaves;
+  rt_fill_leaf_records(s);
+  return RT_OK;
+}

@@ -252,6 +252,10 @@ class Scene:
         return nodes, order
 
     # ---- device -----------------------------------------------------------------------
+    def rebuild_on_device(self, device=0):
+        """Replaces the host-built tree by a linear BVH built on the GPU (for scenes that change)."""
+        check(lib.rt_scene_rebuild_on_device(self._h, int(device)), "rt_scene_rebuild_on_device")
+
     def upload(self, device=0):
         check(lib.rt_scene_upload(self._h, int(device)), "rt_scene_upload")
 

@@ -1,0 +1,102 @@
+"""The acceleration structure built on the GPU (rt_scene_rebuild_on_device) must be a valid tree
+and leave every result of the library unchanged: the nearest hit does not depend on the tree."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+import raytracer_amd as rt
+from raytracer_amd import _ffi, scenes
+from test_host_parity import _adversarial_rays, _check_tree
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.parametrize("name", ["spot", "sphere_floor", "ogre"])
+def test_device_built_tree_is_valid_and_changes_no_result(oracle, name):
+    if rt.device_count() < 1:
+        pytest.fail("no HIP device visible")
+    host = scenes.build(name)
+    dev = scenes.build(name)
+    dev.rebuild_on_device(0)
+    i = dev.info()
+    assert i.n_triangles == host.info().n_triangles and 0 < i.bvh_nodes < i.n_triangles and i.bvh_depth <= 62
+    nodes, order = dev.export_bvh()
+    tv = dev.export_flat()[0]
+    assert sorted(order.tolist()) == list(range(i.n_triangles))
+    _check_tree(nodes, order, i.n_triangles, tv, i.bvh_depth)
+
+    # the CPU restatement of the traversal over the device-built tree equals brute force ...
+    o = oracle.OracleScene.build(name)
+    rng = np.random.default_rng(7)
+    org, d = _adversarial_rays(rng, tv, 1500)
+    got, _ = o.bvh_hit(nodes, order, 0, org, d)
+    want = o.hit(org, d, oracle.HIT_BRUTE)
+    mesh = want["tri"] >= 0  # the restatement covers the triangles; spheres are tested outside the tree
+    for f in ("obj", "tri", "t", "u", "v"):
+        assert got[f][mesh].tobytes() == want[f][mesh].tobytes(), f
+    # ... and the kernels give the same bits with either tree
+    assert dev.hit(org, d).tobytes() == host.hit(org, d).tobytes()
+    w, h = (160, 120) if name == "spot" else (96, 54)
+    p = rt.render_params(width=w, height=h, spp=3, seed=21)
+    for a, b in zip(dev.primary_hits(p), host.primary_hits(p)):
+        assert a.tobytes() == b.tobytes()
+    ca = np.zeros((h, w, 3)); cb = np.zeros((h, w, 3))
+    assert dev.render(ca, p) == host.render(cb, p)
+    assert ca.tobytes() == cb.tobytes()
+
+
+def _scene(tv, oracle=None):
+    mat = rt.Opaque((0.5, 0.5, 0.5), 0, 1, 0)
+    k = len(tv)
+    tn = np.tile(np.array([0, 0, 1.0]), (k, 3, 1)); tuv = np.zeros((k, 3, 2))
+    return rt.Scene.from_desc([_ffi.RT_OBJ_MESH], [mat], tv, tn, tuv, [0] * k, list(range(k)), np.zeros((0, 4)), [])
+
+
+def test_small_and_degenerate_inputs(oracle):
+    one = np.array([[-1, -1, -2], [1, -1, -2], [0, 1, -2]], dtype=np.float64)
+    co, cd = oracle.camera_rays(32, 24)
+    rng = np.random.default_rng(3)
+    cases = {
+        "one triangle": one[None],
+        "three triangles (a single leaf)": one[None] + rng.normal(size=(3, 1, 3)) * 0.3,
+        "five triangles": one[None] + rng.normal(size=(5, 1, 3)) * 0.3,
+        "forty coincident triangles (equal Morton codes)": np.tile(one, (40, 1, 1)),
+        "a line of equal centres and one far away": np.concatenate([np.tile(one, (9, 1, 1)), one[None] + 100.0]),
+    }
+    for what, tv in cases.items():
+        a, b = _scene(tv), _scene(tv)
+        b.rebuild_on_device(0)
+        i = b.info()
+        nodes, order = b.export_bvh()
+        assert sorted(order.tolist()) == list(range(len(tv))), what
+        _check_tree(nodes, order, len(tv), b.export_flat()[0], i.bvh_depth)
+        assert b.hit(co, cd).tobytes() == a.hit(co, cd).tobytes(), what
+    # spheres only: nothing to build, nothing changes
+    mat = rt.Opaque((0.5, 0.5, 0.5), 0, 1, 0)
+    s = rt.Scene.from_desc([_ffi.RT_OBJ_SPHERE], [mat], np.zeros((0, 9)), [], [], [], [], [[0, 0, -3, 1]], [0])
+    want = s.hit(co, cd).tobytes()
+    s.rebuild_on_device(0)
+    assert s.info().bvh_nodes == 0 and s.hit(co, cd).tobytes() == want
+    with pytest.raises(rt.RtError, match="out of range"):
+        s.rebuild_on_device(99)
+
+
+def test_million_triangle_scene_builds_in_milliseconds():
+    s = scenes.build("spot_grid:14x14")
+    t0 = time.perf_counter()
+    s.rebuild_on_device(0)
+    first = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    s.rebuild_on_device(0)
+    again = time.perf_counter() - t0
+    i = s.info()
+    print(f"device build of {i.n_triangles} triangles: {first * 1e3:.1f} ms, again {again * 1e3:.1f} ms; "
+          f"{i.bvh_nodes} nodes, depth {i.bvh_depth}")
+    assert i.bvh_depth <= 62 and again < 2.0
+    p = rt.render_params(width=160, height=90, spp=1, seed=1)
+    host = scenes.build("spot_grid:14x14")
+    for a, b in zip(s.primary_hits(p), host.primary_hits(p)):
+        assert a.tobytes() == b.tobytes()

@@ -19,9 +19,13 @@ ap.add_argument("--spp", type=int, default=64)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--forms", default="wave,mega,noregen")
 ap.add_argument("--count", action="store_true")
+ap.add_argument("--device-build", action="store_true", help="replace the host-built tree by the GPU-built linear BVH")
 a = ap.parse_args()
 s = scenes.build(a.scene)
+if a.device_build:
+    s.rebuild_on_device(0)
 s.upload(0)
+print(f"tree: {s.info().bvh_nodes} nodes, {s.info().bvh_leaves} leaves, depth {s.info().bvh_depth}")
 canvas = torch.zeros((a.height, a.width, 3), dtype=torch.float64, device="cuda")
 KIND = {0: "first", 1: "bounce", 2: "tail", 3: "single", 4: "resolve"}
 FORMS = {"wave": 0, "mega": _ffi.RT_FLAG_MEGAKERNEL, "noregen": _ffi.RT_FLAG_NO_REGEN}

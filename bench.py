@@ -278,7 +278,7 @@ def main():
                 },
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported with the one-GPU line only
             out["cpu_baseline"] = cpu_baseline(scene_name, W, H, spp, args.cpu_sample_spp)
         print(json.dumps(out), flush=True)
     if world > 1:

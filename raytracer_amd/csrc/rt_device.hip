@@ -8,6 +8,7 @@
 //                  wavefront form: one launch per bounce over a compacted queue of live paths
 //   k_paths        the same loop as ONE kernel (per-lane bounce loop, optionally with lanes that
 //                  finish a path pulling the next one from a work counter) — kept for A/B
+//   k_gather       compacts the last queued records so that the tail can run on a side stream
 //   k_resolve      the per-pixel sums of src/main.rs:1020-1037 in sample order
 //
 // HBM layout: see rt_types.h. The per-sample radiance buffer is [n_paths][3] binary64, where

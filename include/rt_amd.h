@@ -12,6 +12,10 @@
  *   PolygonMesh::translate src/main.rs:660-664  -> rt_mesh_translate
  *   Object::from_mesh     src/main.rs:463-469   -> rt_objects_push_mesh
  *   Object::sphere        src/main.rs:454-461   -> rt_objects_push_sphere
+ *   image::io::Reader::open(..).decode()  src/main.rs:1226-1232 -> rt_image_load_png
+ *   sphere_scene / lens_scene             src/main.rs:1223-1450 -> rt_scene_file_load (scenes as data)
+ *   impl Into<Rgba<u8>> for RGBA + display loop  src/main.rs:29-37, 1099-1112 -> rt_quantize_rgba8
+ *   BVH::build (crate bvh) src/main.rs:771       -> inside rt_scene_create; rt_scene_rebuild_on_device
  *
  * Conventions: every function returns RT_OK (0) or a negative RT_ERR_* code and never unwinds
  * across the boundary; rt_last_error() returns a thread-local message for the last failure.

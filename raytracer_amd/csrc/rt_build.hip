@@ -217,7 +217,11 @@ struct DevMem {  // frees what a failed or finished build allocated
 
 }  // namespace
 
+static int rt_scene_rebuild_on_device_body(rt_scene* s, int device);
 extern "C" int rt_scene_rebuild_on_device(rt_scene* s, int device) {
+  return rt_guard("rt_scene_rebuild_on_device", [&] { return rt_scene_rebuild_on_device_body(s, device); });
+}
+static int rt_scene_rebuild_on_device_body(rt_scene* s, int device) {
   if (!s) {
     rt_set_error("rt_scene_rebuild_on_device: null scene");
     return RT_ERR_INVALID;

@@ -160,7 +160,11 @@ static int upload_array(DeviceScene* d, const T* src, size_t n, const T** out) {
   return RT_OK;
 }
 
+static int rt_scene_upload_body(rt_scene* s, int device);
 extern "C" int rt_scene_upload(rt_scene* s, int device) {
+  return rt_guard("rt_scene_upload", [&] { return rt_scene_upload_body(s, device); });
+}
+static int rt_scene_upload_body(rt_scene* s, int device) {
   if (!s) {
     rt_set_error("rt_scene_upload: null scene");
     return RT_ERR_INVALID;
@@ -1325,15 +1329,27 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
   return RT_OK;
 }
 
+static int rt_render_device_body(rt_scene* s, const rt_render_params* p, double* device_canvas, void* stream);
 extern "C" int rt_render_device(rt_scene* s, const rt_render_params* p, double* device_canvas, void* stream) {
+  return rt_guard("rt_render_device", [&] { return rt_render_device_body(s, p, device_canvas, stream); });
+}
+static int rt_render_device_body(rt_scene* s, const rt_render_params* p, double* device_canvas, void* stream) {
   return render_impl(s, p, device_canvas, nullptr, (hipStream_t)stream, "rt_render_device");
 }
 
+static int rt_render_sum_f32_device_body(rt_scene* s, const rt_render_params* p, float* device_sum, void* stream);
 extern "C" int rt_render_sum_f32_device(rt_scene* s, const rt_render_params* p, float* device_sum, void* stream) {
+  return rt_guard("rt_render_sum_f32_device", [&] { return rt_render_sum_f32_device_body(s, p, device_sum, stream); });
+}
+static int rt_render_sum_f32_device_body(rt_scene* s, const rt_render_params* p, float* device_sum, void* stream) {
   return render_impl(s, p, nullptr, device_sum, (hipStream_t)stream, "rt_render_sum_f32_device");
 }
 
+static int rt_render_accumulate_body(rt_scene* s, const rt_render_params* p, double* canvas, uint64_t* rays_out);
 extern "C" int rt_render_accumulate(rt_scene* s, const rt_render_params* p, double* canvas, uint64_t* rays_out) {
+  return rt_guard("rt_render_accumulate", [&] { return rt_render_accumulate_body(s, p, canvas, rays_out); });
+}
+static int rt_render_accumulate_body(rt_scene* s, const rt_render_params* p, double* canvas, uint64_t* rays_out) {
   int rc = require_device(s, "rt_render_accumulate");
   if (rc != RT_OK) return rc;
   if ((rc = check_params(p, "rt_render_accumulate")) != RT_OK) return rc;
@@ -1358,7 +1374,11 @@ extern "C" int rt_render_accumulate(rt_scene* s, const rt_render_params* p, doub
   return RT_OK;
 }
 
+static int rt_trace_body(rt_scene* s, const double* org3, const double* dir3, size_t n, rt_hit* out);
 extern "C" int rt_trace(rt_scene* s, const double* org3, const double* dir3, size_t n, rt_hit* out) {
+  return rt_guard("rt_trace", [&] { return rt_trace_body(s, org3, dir3, n, out); });
+}
+static int rt_trace_body(rt_scene* s, const double* org3, const double* dir3, size_t n, rt_hit* out) {
   int rc = require_device(s, "rt_trace");
   if (rc != RT_OK) return rc;
   if (n == 0) return RT_OK;
@@ -1392,7 +1412,11 @@ extern "C" int rt_trace(rt_scene* s, const double* org3, const double* dir3, siz
   return RT_OK;
 }
 
+static int rt_primary_hits_body(rt_scene* s, const rt_render_params* p, int32_t* obj, int32_t* tri, double* t, double* u, double* v);
 extern "C" int rt_primary_hits(rt_scene* s, const rt_render_params* p, int32_t* obj, int32_t* tri, double* t, double* u, double* v) {
+  return rt_guard("rt_primary_hits", [&] { return rt_primary_hits_body(s, p, obj, tri, t, u, v); });
+}
+static int rt_primary_hits_body(rt_scene* s, const rt_render_params* p, int32_t* obj, int32_t* tri, double* t, double* u, double* v) {
   int rc = require_device(s, "rt_primary_hits");
   if (rc != RT_OK) return rc;
   if ((rc = check_params(p, "rt_primary_hits")) != RT_OK) return rc;
@@ -1431,7 +1455,11 @@ extern "C" int rt_primary_hits(rt_scene* s, const rt_render_params* p, int32_t* 
   return RT_OK;
 }
 
+static int rt_scene_wait_body(rt_scene* s);
 extern "C" int rt_scene_wait(rt_scene* s) {
+  return rt_guard("rt_scene_wait", [&] { return rt_scene_wait_body(s); });
+}
+static int rt_scene_wait_body(rt_scene* s) {
   if (!s) {
     rt_set_error("rt_scene_wait: null scene");
     return RT_ERR_INVALID;
@@ -1440,7 +1468,11 @@ extern "C" int rt_scene_wait(rt_scene* s) {
   return finish_run(s->dev);
 }
 
+static int rt_scene_last_stats_body(rt_scene* s, rt_stats* out);
 extern "C" int rt_scene_last_stats(rt_scene* s, rt_stats* out) {
+  return rt_guard("rt_scene_last_stats", [&] { return rt_scene_last_stats_body(s, out); });
+}
+static int rt_scene_last_stats_body(rt_scene* s, rt_stats* out) {
   if (!s || !out) {
     rt_set_error("rt_scene_last_stats: null argument");
     return RT_ERR_INVALID;
@@ -1467,7 +1499,11 @@ extern "C" int rt_scene_last_stats(rt_scene* s, rt_stats* out) {
   return RT_OK;
 }
 
+static int rt_scene_last_timing_body(rt_scene* s, rt_timing* out);
 extern "C" int rt_scene_last_timing(rt_scene* s, rt_timing* out) {
+  return rt_guard("rt_scene_last_timing", [&] { return rt_scene_last_timing_body(s, out); });
+}
+static int rt_scene_last_timing_body(rt_scene* s, rt_timing* out) {
   if (!s || !out) {
     rt_set_error("rt_scene_last_timing: null argument");
     return RT_ERR_INVALID;
@@ -1481,7 +1517,11 @@ extern "C" int rt_scene_last_timing(rt_scene* s, rt_timing* out) {
   return RT_OK;
 }
 
+static int rt_scene_last_launches_body(rt_scene* s, rt_launch_info* out, uint32_t capacity, uint32_t* n_out);
 extern "C" int rt_scene_last_launches(rt_scene* s, rt_launch_info* out, uint32_t capacity, uint32_t* n_out) {
+  return rt_guard("rt_scene_last_launches", [&] { return rt_scene_last_launches_body(s, out, capacity, n_out); });
+}
+static int rt_scene_last_launches_body(rt_scene* s, rt_launch_info* out, uint32_t capacity, uint32_t* n_out) {
   if (!s || !n_out || (capacity && !out)) {
     rt_set_error("rt_scene_last_launches: null argument");
     return RT_ERR_INVALID;

@@ -95,7 +95,11 @@ static bool parse_face_item(const std::string& t, std::vector<uint64_t>& out) {
   return true;
 }
 
+static int rt_mesh_load_obj_body(const char* path, rt_mesh** out);
 extern "C" int rt_mesh_load_obj(const char* path, rt_mesh** out) {
+  return rt_guard("rt_mesh_load_obj", [&] { return rt_mesh_load_obj_body(path, out); });
+}
+static int rt_mesh_load_obj_body(const char* path, rt_mesh** out) {
   if (!path || !out) {
     rt_set_error("rt_mesh_load_obj: null argument");
     return RT_ERR_INVALID;
@@ -191,7 +195,11 @@ extern "C" int rt_mesh_load_obj(const char* path, rt_mesh** out) {
   return RT_OK;
 }
 
+static int rt_mesh_clone_body(const rt_mesh* mesh, rt_mesh** out);
 extern "C" int rt_mesh_clone(const rt_mesh* mesh, rt_mesh** out) {
+  return rt_guard("rt_mesh_clone", [&] { return rt_mesh_clone_body(mesh, out); });
+}
+static int rt_mesh_clone_body(const rt_mesh* mesh, rt_mesh** out) {
   if (!mesh || !out) {
     rt_set_error("rt_mesh_clone: null argument");
     return RT_ERR_INVALID;
@@ -270,7 +278,11 @@ struct rt_objects {
   std::vector<HostTexture> textures;
 };
 
+static int rt_objects_create_body(rt_objects** out);
 extern "C" int rt_objects_create(rt_objects** out) {
+  return rt_guard("rt_objects_create", [&] { return rt_objects_create_body(out); });
+}
+static int rt_objects_create_body(rt_objects** out) {
   if (!out) {
     rt_set_error("rt_objects_create: null argument");
     return RT_ERR_INVALID;
@@ -280,7 +292,11 @@ extern "C" int rt_objects_create(rt_objects** out) {
 }
 extern "C" void rt_objects_destroy(rt_objects* objs) { delete objs; }
 
+static int rt_objects_add_texture_body(rt_objects* objs, const uint8_t* rgba, uint32_t w, uint32_t h);
 extern "C" int rt_objects_add_texture(rt_objects* objs, const uint8_t* rgba, uint32_t w, uint32_t h) {
+  return rt_guard("rt_objects_add_texture", [&] { return rt_objects_add_texture_body(objs, rgba, w, h); });
+}
+static int rt_objects_add_texture_body(rt_objects* objs, const uint8_t* rgba, uint32_t w, uint32_t h) {
   if (!objs || !rgba || w == 0 || h == 0) {
     rt_set_error("rt_objects_add_texture: null argument or empty texture");
     return RT_ERR_INVALID;
@@ -301,7 +317,11 @@ static bool material_ok(const rt_material* m, size_t n_textures) {
   return true;
 }
 
+static int rt_objects_push_mesh_body(rt_objects* objs, const rt_mesh* mesh, const rt_material* mat);
 extern "C" int rt_objects_push_mesh(rt_objects* objs, const rt_mesh* mesh, const rt_material* mat) {
+  return rt_guard("rt_objects_push_mesh", [&] { return rt_objects_push_mesh_body(objs, mesh, mat); });
+}
+static int rt_objects_push_mesh_body(rt_objects* objs, const rt_mesh* mesh, const rt_material* mat) {
   if (!objs || !mesh || !material_ok(mat, objs->textures.size())) {
     rt_set_error("rt_objects_push_mesh: null argument or invalid material");
     return RT_ERR_INVALID;
@@ -316,7 +336,11 @@ extern "C" int rt_objects_push_mesh(rt_objects* objs, const rt_mesh* mesh, const
   return (int)objs->items.size() - 1;
 }
 
+static int rt_objects_push_sphere_body(rt_objects* objs, const double centre[3], double radius, const rt_material* mat);
 extern "C" int rt_objects_push_sphere(rt_objects* objs, const double centre[3], double radius, const rt_material* mat) {
+  return rt_guard("rt_objects_push_sphere", [&] { return rt_objects_push_sphere_body(objs, centre, radius, mat); });
+}
+static int rt_objects_push_sphere_body(rt_objects* objs, const double centre[3], double radius, const rt_material* mat) {
   if (!objs || !centre || !material_ok(mat, objs->textures.size())) {
     rt_set_error("rt_objects_push_sphere: null argument or invalid material");
     return RT_ERR_INVALID;

@@ -158,7 +158,11 @@ extern "C" void rt_render_params_default(rt_render_params* p) {
   p->dof_strength = 0.0; // src/main.rs:1048
 }
 
+static int rt_scene_file_load_body(const char* path, rt_objects** out, rt_render_params* params, uint32_t* its);
 extern "C" int rt_scene_file_load(const char* path, rt_objects** out, rt_render_params* params, uint32_t* its) {
+  return rt_guard("rt_scene_file_load", [&] { return rt_scene_file_load_body(path, out, params, its); });
+}
+static int rt_scene_file_load_body(const char* path, rt_objects** out, rt_render_params* params, uint32_t* its) {
   if (!path || !out) {
     rt_set_error("rt_scene_file_load: null argument");
     return RT_ERR_INVALID;

@@ -102,6 +102,26 @@ struct rt_scene {
 
 // rt_host.cpp
 void rt_set_error(const char* fmt, ...);
+
+// Nothing may unwind across the C boundary: an entry point whose body can throw (container
+// growth, mostly) runs it through this.
+#include <exception>
+#include <new>
+template <class F>
+static inline int rt_guard(const char* who, F&& body) noexcept {
+  try {
+    return body();
+  } catch (const std::bad_alloc&) {
+    rt_set_error("%s: out of host memory", who);
+    return RT_ERR_OOM;
+  } catch (const std::exception& e) {
+    rt_set_error("%s: %s", who, e.what());
+    return RT_ERR_INVALID;
+  } catch (...) {
+    rt_set_error("%s: unexpected exception", who);
+    return RT_ERR_INVALID;
+  }
+}
 void rt_fill_leaf_records(rt_scene* s);
 double rt_scene_box_pad(const rt_scene* s);
 // rt_device.hip

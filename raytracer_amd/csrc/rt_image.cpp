@@ -110,6 +110,12 @@ int decode_png(const std::vector<uint8_t>& file, const char* path, rt_image* img
   }
   const size_t bpp = (size_t)(channels * depth + 7) / 8;              // bytes per complete pixel, >= 1
   const size_t stride = ((size_t)w * channels * depth + 7) / 8;       // bytes per scanline
+  // deflate cannot expand more than about 1032 times: a header that promises more pixels than the
+  // compressed data can hold is damaged, and must not decide how much memory is asked for
+  if (w > (1u << 20) || h > (1u << 20) || (stride + 1) * (size_t)h > idat.size() * 1100u + 65536u) {
+    rt_set_error("%s: PNG header (%ux%u) does not fit its %zu bytes of image data", path, w, h, idat.size());
+    return RT_ERR_IO;
+  }
   std::vector<uint8_t> raw((stride + 1) * (size_t)h);
   uLongf raw_len = (uLongf)raw.size();
   const int zrc = uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size());

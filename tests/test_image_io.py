@@ -122,6 +122,9 @@ def test_refusals(tmp_path):
     bad.write_bytes(_png(2, 2, 8, 2, [(0, [0] * 6)]))  # one scanline short
     with pytest.raises(rt.RtError, match="inflate"):
         rt.load_png(bad)
+    bad.write_bytes(_png(200000, 200000, 8, 2, [(0, [0] * 6)]))  # a header promising 120 GB for 20 bytes of data
+    with pytest.raises(rt.RtError, match="does not fit"):
+        rt.load_png(bad)
     bad.write_bytes(_png(1, 1, 8, 2, [(7, [0] * 3)]))
     with pytest.raises(rt.RtError, match="filter"):
         rt.load_png(bad)

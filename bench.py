@@ -49,6 +49,9 @@ def main():
     ap.add_argument("--workload", default="sphere_floor_1080p_64spp", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-spp", type=int, default=0, help="spp of the CPU baseline sample (0 = auto)")
+    ap.add_argument("--split", default="samples", choices=["samples", "tiles"],
+                    help="N > 1: 'samples' = every rank renders the frame with its own samples (weak scaling, the default); "
+                         "'tiles' = the frame's 64x64 tiles are dealt round-robin over the ranks (strong scaling)")
     ap.add_argument("--form", default="wave", choices=["wave", "mega", "noregen"], help="scheduling form (A/B); default wavefront")
     args = ap.parse_args()
 
@@ -87,7 +90,9 @@ def main():
 
     def frame_params(step, flags):
         p = rt.render_params(width=W, height=H, spp=spp, first_sample=step * spp * world, seed=0, flags=flags | base_flags)
-        return parallel.weak_samples(p, rank, world) if world > 1 else p
+        if world == 1:
+            return p
+        return parallel.shard_tiles(p, rank, world, 64) if args.split == "tiles" else parallel.weak_samples(p, rank, world)
 
     canvas = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda") if world == 1 else None
     # N > 1: two sum buffers, so that the all-reduce of one frame runs (on the collective's own
@@ -236,7 +241,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if (world > 1 and args.split == "tiles") else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "reference scene files (assets/), counter-based sampling seed 0",
@@ -246,7 +251,10 @@ def main():
                 "spheres": int(info.n_spheres),
                 "bvh_nodes": int(info.bvh_nodes),
                 "frames": "pipelined run (tail and canvas sum of a frame overlap the next frame)" if pipelined else "one after the other",
-                "sharding": "none" if world == 1 else f"samples: {world} x {spp} spp, one RCCL all-reduce(sum, fp32, {W * H * 3 * 4 / 1e6:.1f} MB) per frame",
+                "sharding": "none" if world == 1 else (
+                    f"tiles: 64x64 tiles dealt round-robin over {world} ranks at {spp} spp, disjoint pixels combined by one RCCL all-reduce(sum, fp32, {W * H * 3 * 4 / 1e6:.1f} MB) per frame"
+                    if args.split == "tiles" else
+                    f"samples: {world} x {spp} spp, one RCCL all-reduce(sum, fp32, {W * H * 3 * 4 / 1e6:.1f} MB) per frame"),
                 "form": FORM_NAMES[args.form],
             },
             "sec_per_frame": round(elapsed / args.steps, 5),

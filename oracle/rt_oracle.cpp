@@ -9,7 +9,8 @@
 // file follows src/main.rs function by function, in binary64 with no fused multiply-add
 // (compile with -ffp-contract=off), and is pinned only by (1) analytic known-answer vectors
 // derived from the reference's formulas and (2) a block-mean comparison with the screenshot
-// images/20220206_170941.png the reference's authors committed.
+// images/20220206_170941.png the reference's authors committed (mean absolute difference 0.003
+// at 16 samples per pixel, no brightness bias; tests/test_oracle_kat.py).
 //
 // Two deliberate substitutions, both forced:
 //   * rand::thread_rng() (src/main.rs:266-267, 859, 871-873, 956, 995-997, 1007-1008) is an

@@ -145,28 +145,28 @@ def test_primary_hit_fixtures(oracle):
 
 
 def test_screenshot_pin(oracle):
-    """The oracle's converged Spot image against 8x8 block means of the screenshot the reference's
-    authors committed (images/20220206_170941.png). The screenshot used the 20000^2 texture and an
-    unknown sample count, so the comparison is statistical: mean absolute block difference."""
+    """The oracle's Spot image against the screenshot the reference's authors committed
+    (images/20220206_170941.png, kept as 8x8 block means). Rendered at the screenshot's own
+    1600x1200, quantised per pixel the way the reference quantises (truncation to u8,
+    src/main.rs:32-35), then averaged over the same blocks. Two of the reference's own screenshots
+    of this scene (170941 and 170012) differ by 0.0005 in this measure; what remains here is
+    sampling noise (16 samples per pixel) and the 20000^2 texture the screenshot was made with."""
     from PIL import Image
 
     import raytracer_amd as rt
 
     ref = np.asarray(Image.open(os.path.join(HERE, "golden", "ref_screenshot_blocks_200x150.png")), dtype=np.float64) / 255.0
     s = oracle.OracleScene.build("spot")
-    p = rt.render_params(width=200, height=150, spp=256, seed=3)
-    c = np.zeros((150, 200, 3))
-    s.render(c, p, threads=8, mode=oracle.HIT_REFLIKE)
-    img = np.clip(c, 0.0, 1.0)
-    diff = np.abs(img - ref)
-    # measured: 0.0069 at 256 spp (0.0129 at 48 spp: sampling noise), of which 0.002 is the
-    # screenshot's truncating u8 quantisation (src/main.rs:32-35)
-    assert diff.mean() < 0.009, diff.mean()
-    assert abs((img - ref).mean() - 0.5 / 255) < 0.0015
-    # structure, not just average colour: block-wise correlation per channel
+    c = np.zeros((1200, 1600, 3))
+    s.render(c, rt.render_params(width=1600, height=1200, spp=16, seed=3), threads=8, mode=oracle.HIT_REFLIKE)
+    img = (np.floor(np.clip(c, 0.0, 1.0) * 255.0) / 255.0).reshape(150, 8, 200, 8, 3).mean(axis=(1, 3))
+    diff = img - ref
+    # measured: mean |diff| 0.0028, mean diff -0.0002, 99th percentile 0.018, correlation 0.9995
+    assert np.abs(diff).mean() < 0.0036, np.abs(diff).mean()
+    assert abs(diff.mean()) < 0.0006, diff.mean()  # no brightness bias: same sky, same albedo, same quantiser
+    assert np.percentile(np.abs(diff), 99) < 0.026
     for ch in range(3):
-        assert np.corrcoef(img[..., ch].ravel(), ref[..., ch].ravel())[0, 1] > 0.985
-    assert np.percentile(diff, 99) < 0.08
+        assert np.corrcoef(img[..., ch].ravel(), ref[..., ch].ravel())[0, 1] > 0.999
 
 
 @pytest.mark.parametrize("name", ["spot", "lens", "sphere_floor", "ogre"])

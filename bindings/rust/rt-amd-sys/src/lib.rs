@@ -26,6 +26,10 @@ pub const RT_FLAG_NO_REGEN: u32 = 8;
 pub const RT_FLAG_MEGAKERNEL: u32 = 16;
 pub const RT_FLAG_PIPELINE: u32 = 32;
 
+pub const RT_GROUP_MAX: u32 = 16;
+pub const RT_SPLIT_SAMPLES: u32 = 0;
+pub const RT_SPLIT_TILES: u32 = 1;
+
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
 pub struct rt_material {
@@ -154,6 +158,7 @@ pub enum rt_image {}
 pub enum rt_mesh {}
 pub enum rt_objects {}
 pub enum rt_scene {}
+pub enum rt_group {}
 
 extern "C" {
     pub fn rt_mesh_load_obj(path: *const c_char, out: *mut *mut rt_mesh) -> c_int;
@@ -197,6 +202,12 @@ extern "C" {
     pub fn rt_render_device(scene: *mut rt_scene, p: *const rt_render_params, device_canvas: *mut f64, stream: *mut c_void) -> c_int;
     pub fn rt_render_sum_f32_device(scene: *mut rt_scene, p: *const rt_render_params, device_sum: *mut f32, stream: *mut c_void) -> c_int;
     pub fn rt_scene_wait(scene: *mut rt_scene) -> c_int;
+    pub fn rt_group_create(scene: *const rt_scene, devices: *const c_int, n_devices: u32, out: *mut *mut rt_group) -> c_int;
+    pub fn rt_group_destroy(group: *mut rt_group);
+    pub fn rt_group_size(group: *const rt_group, n_members: *mut u32) -> c_int;
+    pub fn rt_group_render_accumulate(group: *mut rt_group, p: *const rt_render_params, split: u32, canvas: *mut f64, rays_out: *mut u64) -> c_int;
+    pub fn rt_group_render_device(group: *mut rt_group, p: *const rt_render_params, split: u32, device_canvas: *mut f64, rays_out: *mut u64) -> c_int;
+    pub fn rt_group_member_info(group: *const rt_group, member: u32, device: *mut c_int, rays: *mut u64, ms: *mut f64) -> c_int;
     pub fn rt_scene_last_stats(scene: *mut rt_scene, out: *mut rt_stats) -> c_int;
     pub fn rt_scene_last_timing(scene: *mut rt_scene, out: *mut rt_timing) -> c_int;
     pub fn rt_scene_last_launches(scene: *mut rt_scene, out: *mut rt_launch_info, capacity: u32, n_out: *mut u32) -> c_int;

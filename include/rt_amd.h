@@ -314,6 +314,44 @@ int rt_scene_last_timing(rt_scene* scene, rt_timing* out);
 /* Per-launch log of the last render call: copies up to `capacity` entries, *n_out = total. */
 int rt_scene_last_launches(rt_scene* scene, rt_launch_info* out, uint32_t capacity, uint32_t* n_out);
 
+/* ---- several GPUs from one process ------------------------------------------------------- */
+
+/* The reference is one process (main, src/main.rs:1054-1128) and spreads render's pixels and
+ * samples over whatever the machine has (rayon, src/main.rs:988, 994). A group does the same
+ * over several GPUs of a node for such a caller: every member holds its own copy of the scene
+ * in its own HBM and renders its share of the frame on a host thread of its own; the first
+ * member's GPU then reads the others' binary32 sums directly over xGMI (peer access, no staging
+ * copies, every link into that GPU used at once) and adds the frame to the canvas. Callers that
+ * run one process per GPU use rt_render_sum_f32_device and their own collective instead. */
+typedef struct rt_group rt_group;
+#define RT_GROUP_MAX 16u
+#define RT_SPLIT_SAMPLES 0u /* member g renders samples [g*spp/n, (g+1)*spp/n) of every pixel    */
+#define RT_SPLIT_TILES 1u   /* member g renders the square tiles whose row-major index % n == g */
+
+/* `devices` lists one HIP device per member; the first is where frames are combined. The scene
+ * is only read (its host arrays are copied to each device) and may be destroyed afterwards.
+ * Naming a device twice is allowed (two members then share that GPU): meant for rehearsing a
+ * group on a machine with fewer GPUs. RT_ERR_HIP if the first device cannot reach another one
+ * by peer access. */
+int rt_group_create(const rt_scene* scene, const int* devices, uint32_t n_devices, rt_group** out);
+void rt_group_destroy(rt_group* group);
+int rt_group_size(const rt_group* group, uint32_t* n_members);
+
+/* render::<W,H> over the group, src/main.rs:977-1039: canvas[v][u][c] += mean over p->spp
+ * samples, canvas a host buffer as for rt_render_accumulate. p describes the whole frame:
+ * tile_rank/tile_ranks must be zero, tile_size is the tile edge of RT_SPLIT_TILES (0: 64),
+ * RT_FLAG_PIPELINE is ignored. Every member's sum of samples is rounded to binary32 once per
+ * pixel before the members are added in binary64, so a frame agrees with a single GPU's to
+ * about 1e-7 relative, not bit for bit. Returns when the canvas is complete. */
+int rt_group_render_accumulate(rt_group* group, const rt_render_params* p, uint32_t split, double* canvas,
+                               uint64_t* rays_out);
+/* Same with the canvas in the memory of the group's first device. */
+int rt_group_render_device(rt_group* group, const rt_render_params* p, uint32_t split, double* device_canvas,
+                           uint64_t* rays_out);
+/* What member `member` did in the last frame: its device, the nearest-hit queries it answered
+ * and the wall-clock time its share took — the load balance of the split. */
+int rt_group_member_info(const rt_group* group, uint32_t member, int* device, uint64_t* rays, double* ms);
+
 /* impl Into<Rgba<u8>> for RGBA, src/main.rs:29-37, applied to canvas / its as the display loop
  * does at src/main.rs:1106-1112. Host buffers; out is [height][width][4]. */
 int rt_quantize_rgba8(const double* canvas, uint32_t width, uint32_t height, uint32_t its, uint8_t* out);

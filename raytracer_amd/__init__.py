@@ -9,6 +9,7 @@ from . import _ffi  # noqa: F401  (loads librt_amd.so or raises)
 from ._ffi import RtError  # noqa: F401
 from .host import (  # noqa: F401
     Dielectric,
+    Group,
     Objects,
     Opaque,
     PolygonMesh,

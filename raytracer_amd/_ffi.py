@@ -28,6 +28,10 @@ RT_FLAG_NO_REGEN = 8
 RT_FLAG_MEGAKERNEL = 16
 RT_FLAG_PIPELINE = 32
 
+RT_GROUP_MAX = 16
+RT_SPLIT_SAMPLES = 0
+RT_SPLIT_TILES = 1
+
 
 class rt_material(C.Structure):
     _fields_ = [
@@ -182,6 +186,12 @@ SIGNATURES = {
     "rt_render_device": (C.c_int, [_P, C.POINTER(rt_render_params), _P, _P]),
     "rt_render_sum_f32_device": (C.c_int, [_P, C.POINTER(rt_render_params), _P, _P]),
     "rt_scene_wait": (C.c_int, [_P]),
+    "rt_group_create": (C.c_int, [_P, C.POINTER(C.c_int), C.c_uint32, C.POINTER(_P)]),
+    "rt_group_destroy": (None, [_P]),
+    "rt_group_size": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
+    "rt_group_render_accumulate": (C.c_int, [_P, C.POINTER(rt_render_params), C.c_uint32, _P, C.POINTER(C.c_uint64)]),
+    "rt_group_render_device": (C.c_int, [_P, C.POINTER(rt_render_params), C.c_uint32, _P, C.POINTER(C.c_uint64)]),
+    "rt_group_member_info": (C.c_int, [_P, C.c_uint32, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
     "rt_scene_last_stats": (C.c_int, [_P, C.POINTER(rt_stats)]),
     "rt_scene_last_timing": (C.c_int, [_P, C.POINTER(rt_timing)]),
     "rt_scene_last_launches": (C.c_int, [_P, C.POINTER(rt_launch_info), C.c_uint32, C.POINTER(C.c_uint32)]),

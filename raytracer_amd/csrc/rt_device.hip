@@ -160,12 +160,13 @@ static int upload_array(DeviceScene* d, const T* src, size_t n, const T** out) {
   return RT_OK;
 }
 
-static int rt_scene_upload_body(rt_scene* s, int device);
 extern "C" int rt_scene_upload(rt_scene* s, int device) {
-  return rt_guard("rt_scene_upload", [&] { return rt_scene_upload_body(s, device); });
+  return rt_guard("rt_scene_upload", [&] { return rt_device_scene_upload_from(s, s, device); });
 }
-static int rt_scene_upload_body(rt_scene* s, int device) {
-  if (!s) {
+// Uploads the arrays of `s` to `device` and hangs the device half on `target` (normally s itself;
+// a group hangs one device half per member on otherwise empty scenes).
+int rt_device_scene_upload_from(const rt_scene* s, rt_scene* target, int device) {
+  if (!s || !target) {
     rt_set_error("rt_scene_upload: null scene");
     return RT_ERR_INVALID;
   }
@@ -178,10 +179,10 @@ static int rt_scene_upload_body(rt_scene* s, int device) {
     rt_set_error("rt_scene_upload: device %d out of range (0..%d)", device, n - 1);
     return RT_ERR_INVALID;
   }
-  if (s->dev && s->dev->device == device) return RT_OK;
-  if (s->dev) {
-    rt_device_scene_free(s->dev);
-    s->dev = nullptr;
+  if (target->dev && target->dev->device == device) return RT_OK;
+  if (target->dev) {
+    rt_device_scene_free(target->dev);
+    target->dev = nullptr;
   }
   HIP_TRY(hipSetDevice(device));
   DeviceScene* d = new (std::nothrow) DeviceScene();
@@ -224,7 +225,7 @@ static int rt_scene_upload_body(rt_scene* s, int device) {
     rt_set_error("rt_scene_upload: hipHostMalloc of the counter mirror failed");
     return fail(RT_ERR_HIP);
   }
-  s->dev = d;
+  target->dev = d;
   return RT_OK;
 }
 

@@ -1,0 +1,329 @@
+// rt_group.hip — one frame over several GPUs driven from ONE process.
+//
+// The reference is a single process whose render (src/main.rs:977-1039) spreads independent
+// pixels and samples over the machine's cores (rayon, src/main.rs:988, 994). A caller shaped
+// like that reaches the GPUs of a node through a group: one member per GPU, each with its own
+// copy of the read-only scene in its own HBM, its own stream and — because a render call reads
+// its queue counters back between bounces — its own host thread for the length of a frame.
+//
+// Exchange step. Every member leaves a binary32 [H][W][3] sum of its samples in its own HBM.
+// The GPUs of a node are fully connected by xGMI links, so instead of a ring the first member's
+// GPU simply reads: k_combine runs there, loads each element from every member's buffer through
+// peer mappings (all links into that GPU busy at once, no staging copies, nothing written
+// remotely), adds them in member order in binary64 and adds the mean to the canvas. With the
+// tile split it loads an element only from the member that owns its tile, so one frame's worth
+// of data crosses the links in total.
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "rt_types.h"
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      rt_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return RT_ERR_HIP;                                                                       \
+    }                                                                                          \
+  } while (0)
+
+namespace {
+
+struct SumTable {
+  const float* sum[RT_GROUP_MAX];
+};
+
+// canvas[e] += (sum over members, or the owner's value) / divisor, one binary32 element per lane:
+// a wave reads 256 consecutive bytes of each member's buffer.
+__global__ __launch_bounds__(256) void k_combine(SumTable t, uint32_t n_members, uint64_t n_elems, uint32_t width,
+                                                 uint32_t tile_size, uint32_t tiles_x, double divisor,
+                                                 double* __restrict__ canvas) {
+  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_elems) return;
+  double acc = 0.0;
+  if (tile_size == 0) {
+    for (uint32_t g = 0; g < n_members; ++g) acc += (double)t.sum[g][e];
+  } else {
+    const uint64_t pixel = e / 3u;
+    const uint32_t x = (uint32_t)(pixel % width), y = (uint32_t)(pixel / width);
+    const uint32_t owner = ((y / tile_size) * tiles_x + x / tile_size) % n_members;
+    acc = (double)t.sum[owner][e];
+  }
+  canvas[e] += acc / divisor;
+}
+
+struct Member {
+  rt_scene view;  // no host arrays: only the device half, uploaded from the caller's scene
+  int device = -1;
+  hipStream_t stream = nullptr;
+  float* sum = nullptr;
+  size_t sum_bytes = 0;
+  // last frame
+  int rc = RT_OK;
+  std::string error;
+  uint64_t rays = 0;
+  double ms = 0.0;
+};
+
+}  // namespace
+
+struct rt_group {
+  std::vector<std::unique_ptr<Member>> members;
+  double* stage = nullptr;  // canvas of the host-buffer entry point, on the first device
+  size_t stage_bytes = 0;
+};
+
+static void group_free(rt_group* g) {
+  if (!g) return;
+  for (auto& m : g->members) {
+    if (!m || m->device < 0) continue;
+    (void)hipSetDevice(m->device);
+    if (m->view.dev) rt_device_scene_free(m->view.dev);
+    m->view.dev = nullptr;
+    if (m->sum) (void)hipFree(m->sum);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+  }
+  if (g->stage && !g->members.empty()) {
+    (void)hipSetDevice(g->members[0]->device);
+    (void)hipFree(g->stage);
+  }
+  delete g;
+}
+
+static int rt_group_create_body(const rt_scene* scene, const int* devices, uint32_t n, rt_group** out) {
+  if (out) *out = nullptr;
+  if (!scene || !devices || !out) {
+    rt_set_error("rt_group_create: null argument");
+    return RT_ERR_INVALID;
+  }
+  if (n == 0 || n > RT_GROUP_MAX) {
+    rt_set_error("rt_group_create: a group has 1..%u members, not %u", RT_GROUP_MAX, n);
+    return RT_ERR_INVALID;
+  }
+  const int n_dev = rt_device_count();
+  if (n_dev <= 0) {
+    rt_set_error("rt_group_create: no HIP device is visible; this library has no CPU path");
+    return RT_ERR_NO_DEVICE;
+  }
+  for (uint32_t i = 0; i < n; ++i)
+    if (devices[i] < 0 || devices[i] >= n_dev) {
+      rt_set_error("rt_group_create: device %d out of range (0..%d)", devices[i], n_dev - 1);
+      return RT_ERR_INVALID;
+    }
+  // the first device must be able to read every other member's memory
+  const int root = devices[0];
+  HIP_TRY(hipSetDevice(root));
+  for (uint32_t i = 1; i < n; ++i) {
+    if (devices[i] == root) continue;
+    bool seen = false;
+    for (uint32_t j = 1; j < i; ++j) seen = seen || devices[j] == devices[i];
+    if (seen) continue;
+    int can = 0;
+    HIP_TRY(hipDeviceCanAccessPeer(&can, root, devices[i]));
+    if (!can) {
+      rt_set_error("rt_group_create: device %d cannot access the memory of device %d", root, devices[i]);
+      return RT_ERR_HIP;
+    }
+    const hipError_t e = hipDeviceEnablePeerAccess(devices[i], 0);
+    if (e == hipErrorPeerAccessAlreadyEnabled) {
+      (void)hipGetLastError();
+    } else if (e != hipSuccess) {
+      rt_set_error("rt_group_create: hipDeviceEnablePeerAccess(%d) from device %d failed: %s", devices[i], root, hipGetErrorString(e));
+      return RT_ERR_HIP;
+    }
+  }
+  rt_group* g = new rt_group();
+  for (uint32_t i = 0; i < n; ++i) {
+    g->members.emplace_back(new Member());
+    Member* m = g->members.back().get();
+    int rc = rt_device_scene_upload_from(scene, &m->view, devices[i]);  // leaves devices[i] current
+    if (rc == RT_OK) {
+      m->device = devices[i];
+      if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
+        rt_set_error("rt_group_create: hipStreamCreate on device %d failed", devices[i]);
+        rc = RT_ERR_HIP;
+      }
+    }
+    if (rc != RT_OK) {
+      group_free(g);
+      return rc;
+    }
+  }
+  *out = g;
+  return RT_OK;
+}
+
+extern "C" int rt_group_create(const rt_scene* scene, const int* devices, uint32_t n_devices, rt_group** out) {
+  return rt_guard("rt_group_create", [&] { return rt_group_create_body(scene, devices, n_devices, out); });
+}
+
+extern "C" void rt_group_destroy(rt_group* group) { group_free(group); }
+
+extern "C" int rt_group_size(const rt_group* group, uint32_t* n_members) {
+  if (!group || !n_members) {
+    rt_set_error("rt_group_size: null argument");
+    return RT_ERR_INVALID;
+  }
+  *n_members = (uint32_t)group->members.size();
+  return RT_OK;
+}
+
+extern "C" int rt_group_member_info(const rt_group* group, uint32_t member, int* device, uint64_t* rays, double* ms) {
+  if (!group || member >= group->members.size()) {
+    rt_set_error("rt_group_member_info: no such member");
+    return RT_ERR_INVALID;
+  }
+  const Member& m = *group->members[member];
+  if (device) *device = m.device;
+  if (rays) *rays = m.rays;
+  if (ms) *ms = m.ms;
+  return RT_OK;
+}
+
+// One member's share of a frame, on its own host thread. Errors are kept in the member: the
+// library's error text is per thread.
+static void member_frame(Member* m, rt_render_params mp, size_t sum_bytes) {
+  const auto t0 = std::chrono::steady_clock::now();
+  m->rays = 0;
+  m->error.clear();
+  auto fail = [&](int rc, const char* what) {
+    m->rc = rc;
+    m->error = what ? what : rt_last_error();
+  };
+  m->rc = RT_OK;
+  if (hipSetDevice(m->device) != hipSuccess) return fail(RT_ERR_HIP, "hipSetDevice failed");
+  if (m->sum_bytes < sum_bytes) {
+    if (m->sum) (void)hipFree(m->sum);
+    m->sum = nullptr;
+    m->sum_bytes = 0;
+    if (hipMalloc((void**)&m->sum, sum_bytes) != hipSuccess) return fail(RT_ERR_HIP, "hipMalloc of a member's sum buffer failed");
+    m->sum_bytes = sum_bytes;
+  }
+  if (hipMemsetAsync(m->sum, 0, sum_bytes, m->stream) != hipSuccess) return fail(RT_ERR_HIP, "hipMemsetAsync failed");
+  int rc = rt_render_sum_f32_device(&m->view, &mp, m->sum, m->stream);
+  if (rc != RT_OK) return fail(rc, nullptr);
+  rt_stats st;
+  if ((rc = rt_scene_last_stats(&m->view, &st)) != RT_OK) return fail(rc, nullptr);  // waits for the member's work
+  if (hipStreamSynchronize(m->stream) != hipSuccess) return fail(RT_ERR_HIP, "hipStreamSynchronize failed");
+  m->rays = st.rays;
+  m->ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+static int group_render(rt_group* g, const rt_render_params* p, uint32_t split, double* device_canvas, uint64_t* rays_out,
+                        const char* who) {
+  if (!g || !p || !device_canvas) {
+    rt_set_error("%s: null argument", who);
+    return RT_ERR_INVALID;
+  }
+  if (split != RT_SPLIT_SAMPLES && split != RT_SPLIT_TILES) {
+    rt_set_error("%s: unknown split %u", who, split);
+    return RT_ERR_INVALID;
+  }
+  if (p->tile_rank != 0 || p->tile_ranks > 1) {
+    rt_set_error("%s: tile_rank/tile_ranks belong to the group; describe the whole frame", who);
+    return RT_ERR_INVALID;
+  }
+  if (p->width == 0 || p->height == 0 || p->width > 65536 || p->height > 65536) {
+    rt_set_error("%s: bad image size %ux%u", who, p->width, p->height);
+    return RT_ERR_INVALID;
+  }
+  const uint32_t n = (uint32_t)g->members.size();
+  uint32_t tile = 0;
+  if (split == RT_SPLIT_TILES) {
+    tile = p->tile_size ? p->tile_size : 64u;
+    if (tile % 8u != 0) {
+      rt_set_error("%s: tile_size must be a multiple of 8", who);
+      return RT_ERR_INVALID;
+    }
+  }
+  const uint32_t total = p->spp_total ? p->spp_total : p->spp;
+  const uint64_t n_elems = (uint64_t)p->width * p->height * 3u;
+  const size_t sum_bytes = (size_t)n_elems * sizeof(float);
+
+  std::vector<std::thread> threads;
+  threads.reserve(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    rt_render_params mp = *p;
+    mp.flags &= ~RT_FLAG_PIPELINE;
+    mp.spp_total = total;
+    if (split == RT_SPLIT_SAMPLES) {
+      const uint32_t lo = (uint32_t)(((uint64_t)p->spp * i) / n), hi = (uint32_t)(((uint64_t)p->spp * (i + 1)) / n);
+      mp.first_sample = p->first_sample + lo;
+      mp.spp = hi - lo;
+      mp.tile_size = 0;
+    } else {
+      mp.tile_size = tile;
+      mp.tile_rank = i;
+      mp.tile_ranks = n;
+    }
+    threads.emplace_back(member_frame, g->members[i].get(), mp, sum_bytes);
+  }
+  for (std::thread& t : threads) t.join();
+  uint64_t rays = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const Member& m = *g->members[i];
+    if (m.rc != RT_OK) {
+      rt_set_error("%s: member %u (device %d): %s", who, i, m.device, m.error.c_str());
+      return m.rc;
+    }
+    rays += m.rays;
+  }
+  if (rays_out) *rays_out = rays;
+
+  // every member's sums are complete and visible; combine on the first device
+  Member& root = *g->members[0];
+  HIP_TRY(hipSetDevice(root.device));
+  SumTable t{};
+  for (uint32_t i = 0; i < n; ++i) t.sum[i] = g->members[i]->sum;
+  // a single member in tile mode owns every tile; n == 1 needs no owner arithmetic either way
+  const uint32_t k_tile = (split == RT_SPLIT_TILES && n > 1) ? tile : 0u;
+  const uint32_t tiles_x = k_tile ? (p->width + k_tile - 1) / k_tile : 0u;
+  const uint64_t blocks = (n_elems + 255u) / 256u;
+  hipLaunchKernelGGL(k_combine, dim3((uint32_t)blocks), dim3(256), 0, root.stream, t, n, n_elems, p->width, k_tile, tiles_x,
+                     (double)total, device_canvas);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(root.stream));
+  return RT_OK;
+}
+
+extern "C" int rt_group_render_device(rt_group* group, const rt_render_params* p, uint32_t split, double* device_canvas,
+                                      uint64_t* rays_out) {
+  return rt_guard("rt_group_render_device", [&] { return group_render(group, p, split, device_canvas, rays_out, "rt_group_render_device"); });
+}
+
+static int rt_group_render_accumulate_body(rt_group* g, const rt_render_params* p, uint32_t split, double* canvas, uint64_t* rays_out) {
+  if (!g || !p || !canvas) {
+    rt_set_error("rt_group_render_accumulate: null argument");
+    return RT_ERR_INVALID;
+  }
+  if (p->width == 0 || p->height == 0 || p->width > 65536 || p->height > 65536) {
+    rt_set_error("rt_group_render_accumulate: bad image size %ux%u", p->width, p->height);
+    return RT_ERR_INVALID;
+  }
+  const size_t bytes = (size_t)p->width * p->height * 3u * sizeof(double);
+  HIP_TRY(hipSetDevice(g->members[0]->device));
+  if (g->stage_bytes < bytes) {
+    if (g->stage) (void)hipFree(g->stage);
+    g->stage = nullptr;
+    g->stage_bytes = 0;
+    HIP_TRY(hipMalloc((void**)&g->stage, bytes));
+    g->stage_bytes = bytes;
+  }
+  HIP_TRY(hipMemcpy(g->stage, canvas, bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipDeviceSynchronize());  // the members' streams do not wait for the default stream
+  const int rc = group_render(g, p, split, g->stage, rays_out, "rt_group_render_accumulate");
+  if (rc != RT_OK) return rc;
+  HIP_TRY(hipMemcpy(canvas, g->stage, bytes, hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+
+extern "C" int rt_group_render_accumulate(rt_group* group, const rt_render_params* p, uint32_t split, double* canvas,
+                                          uint64_t* rays_out) {
+  return rt_guard("rt_group_render_accumulate", [&] { return rt_group_render_accumulate_body(group, p, split, canvas, rays_out); });
+}

@@ -5,10 +5,11 @@
 // (src/main.rs:1106-1112) — here written as a PNG file instead of blitted into a window.
 //
 //   rt_render SCENE_FILE [-o OUT.png] [--width W] [--height H] [--spp S] [--its N] [--seed K]
-//             [--max-depth D] [--device I] [--progress]
+//             [--max-depth D] [--device I | --devices I,J,... [--split samples|tiles]] [--progress]
 //
 // Options override the scene file's `render` statement. --progress rewrites OUT.png after
-// every call, as the reference's window refreshes after every render event.
+// every call, as the reference's window refreshes after every render event. --devices renders
+// every frame on a group of GPUs (one member per listed device, the first combines the frame).
 
 #include <hip/hip_runtime.h>
 
@@ -49,6 +50,8 @@ int main(int argc, char** argv) {
   long long o_w = -1, o_h = -1, o_spp = -1, o_its = -1, o_depth = -1, device = 0;
   unsigned long long o_seed = 0;
   bool has_seed = false, progress = false;
+  std::vector<int> devices;
+  uint32_t split = RT_SPLIT_SAMPLES;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
     auto value = [&](long long* dst) {
@@ -67,11 +70,25 @@ int main(int argc, char** argv) {
     else if (a == "--device") ok = value(&device);
     else if (a == "--seed" && i + 1 < argc) { o_seed = std::strtoull(argv[++i], nullptr, 10); has_seed = true; }
     else if (a == "--progress") progress = true;
+    else if (a == "--devices" && i + 1 < argc) {
+      for (const char* c = argv[++i]; ok && *c;) {
+        char* end = nullptr;
+        const long v = std::strtol(c, &end, 10);
+        ok = end != c && v >= 0 && (*end == ',' || *end == '\0');
+        devices.push_back((int)v);
+        c = *end ? end + 1 : end;
+      }
+      ok = ok && !devices.empty();
+    } else if (a == "--split" && i + 1 < argc) {
+      const std::string v = argv[++i];
+      ok = v == "samples" || v == "tiles";
+      split = v == "tiles" ? RT_SPLIT_TILES : RT_SPLIT_SAMPLES;
+    }
     else if (!a.empty() && a[0] != '-' && !scene_path) scene_path = argv[i];
     else ok = false;
     if (!ok) {
       std::fprintf(stderr, "usage: rt_render SCENE_FILE [-o OUT.png] [--width W] [--height H] [--spp S] [--its N] "
-                           "[--seed K] [--max-depth D] [--device I] [--progress]\n");
+                           "[--seed K] [--max-depth D] [--device I | --devices I,J,... [--split samples|tiles]] [--progress]\n");
       return 2;
     }
   }
@@ -99,7 +116,13 @@ int main(int argc, char** argv) {
   rt_scene* scene = nullptr;
   if (rt_scene_from_objects(objs, &scene) != RT_OK) return die("rt_scene_from_objects");
   rt_objects_destroy(objs);
-  if (rt_scene_upload(scene, (int)device) != RT_OK) return die("rt_scene_upload");
+  rt_group* group = nullptr;
+  if (!devices.empty()) {
+    device = devices[0];
+    if (rt_group_create(scene, devices.data(), (uint32_t)devices.size(), &group) != RT_OK) return die("rt_group_create");
+  } else if (rt_scene_upload(scene, (int)device) != RT_OK) {
+    return die("rt_scene_upload");
+  }
   rt_scene_info info;
   rt_scene_get_info(scene, &info);
   const double build_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_build).count();
@@ -126,6 +149,13 @@ int main(int argc, char** argv) {
   for (uint32_t it = 0; it < its; ++it) {
     rt_render_params q = p;
     q.first_sample = p.first_sample + it * p.spp;  // fresh samples of each pixel's stream per call
+    if (group) {
+      uint64_t r = 0;
+      if (rt_group_render_device(group, &q, split, canvas, &r) != RT_OK) return die("rt_group_render_device");
+      rays += r;
+      if (progress && write_frame(out_path.c_str(), canvas, host, rgba, p.width, p.height, it + 1, stream)) return 1;
+      continue;
+    }
     // frame follows frame: let each call's last kernels overlap the next call (a pipelined run)
     q.flags |= RT_FLAG_PIPELINE;
     if (rt_render_device(scene, &q, canvas, stream) != RT_OK) return die("rt_render_device");
@@ -136,7 +166,7 @@ int main(int argc, char** argv) {
       if (write_frame(out_path.c_str(), canvas, host, rgba, p.width, p.height, it + 1, stream)) return 1;
     }
   }
-  if (!progress) {  // waits for the run and reports its totals
+  if (!progress && !group) {  // waits for the run and reports its totals
     rt_stats st;
     if (rt_scene_last_stats(scene, &st) != RT_OK) return die("rt_scene_last_stats");
     rays = st.rays;
@@ -149,6 +179,16 @@ int main(int argc, char** argv) {
   if (!progress && write_frame(out_path.c_str(), canvas, host, rgba, p.width, p.height, its, stream)) return 1;
   std::fprintf(stderr, "rt_render: %ux%u, %u x %u spp, %llu rays in %.3f s (%.1f Mrays/s) -> %s\n", p.width, p.height, its, p.spp,
                (unsigned long long)rays, secs, rays / secs / 1e6, out_path.c_str());
+  if (group) {
+    for (uint32_t i = 0; i < (uint32_t)devices.size(); ++i) {
+      int dev = 0;
+      uint64_t r = 0;
+      double ms = 0.0;
+      rt_group_member_info(group, i, &dev, &r, &ms);
+      std::fprintf(stderr, "rt_render:   member %u on device %d: last frame %llu rays in %.2f ms\n", i, dev, (unsigned long long)r, ms);
+    }
+    rt_group_destroy(group);
+  }
   (void)hipFree(canvas);
   (void)hipStreamDestroy(stream);
   rt_scene_destroy(scene);

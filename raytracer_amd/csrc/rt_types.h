@@ -126,6 +126,7 @@ void rt_fill_leaf_records(rt_scene* s);
 double rt_scene_box_pad(const rt_scene* s);
 // rt_device.hip
 void rt_device_scene_free(DeviceScene* d);
+int rt_device_scene_upload_from(const rt_scene* host, rt_scene* target, int device);
 int rt_device_scene_info(const DeviceScene* d, uint32_t* device_plus_one, uint64_t* bytes);
 #endif
 

@@ -313,6 +313,48 @@ class Scene:
         return t
 
 
+class Group:
+    """Several GPUs of one node driven from this one process, the way the reference's single
+    process spreads render over its cores (src/main.rs:988, 994): one member per listed device,
+    each with its own copy of the scene. The first device combines the frame."""
+
+    def __init__(self, scene, devices):
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        check(lib.rt_group_create(scene._h, devs, len(devices), C.byref(h)), "rt_group_create")
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.rt_group_destroy(self._h)
+            self._h = None
+
+    def __len__(self):
+        n = C.c_uint32()
+        check(lib.rt_group_size(self._h, C.byref(n)), "rt_group_size")
+        return n.value
+
+    def render(self, canvas, params, split=_ffi.RT_SPLIT_SAMPLES):
+        """render::<W,H>(&mut canvas, &scene) over the group: adds the mean of params.spp samples
+        into the host canvas. Returns the number of nearest-hit queries of all members."""
+        assert canvas.dtype == np.float64 and canvas.flags.c_contiguous
+        assert canvas.shape == (params.height, params.width, 3)
+        rays = C.c_uint64()
+        check(lib.rt_group_render_accumulate(self._h, C.byref(params), int(split), _ptr(canvas), C.byref(rays)), "rt_group_render_accumulate")
+        return rays.value
+
+    def render_device(self, device_canvas_ptr, params, split=_ffi.RT_SPLIT_SAMPLES):
+        rays = C.c_uint64()
+        check(lib.rt_group_render_device(self._h, C.byref(params), int(split), C.c_void_p(device_canvas_ptr), C.byref(rays)), "rt_group_render_device")
+        return rays.value
+
+    def member_info(self, member):
+        """(device, nearest-hit queries, milliseconds) of one member's share of the last frame."""
+        dev, rays, ms = C.c_int(), C.c_uint64(), C.c_double()
+        check(lib.rt_group_member_info(self._h, int(member), C.byref(dev), C.byref(rays), C.byref(ms)), "rt_group_member_info")
+        return dev.value, rays.value, ms.value
+
+
 def load_png(path):
     """image::io::Reader::open(path).decode() as [h][w][4] uint8 (src/main.rs:1226-1232)."""
     img = C.c_void_p()

@@ -55,6 +55,7 @@ def header_structs():
 def header_functions():
     text = strip_c(open(HEADER).read())
     text = re.sub(r"typedef struct \w+ \{.*?\}\s*\w+;", "", text, flags=re.S)
+    text = re.sub(r"^[ \t]*#.*$", "", text, flags=re.M)  # preprocessor lines
     out = {}
     for ret, name, args in re.findall(r"([\w\s\*]+?)\b(rt_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text):
         params = []

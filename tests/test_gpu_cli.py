@@ -51,3 +51,25 @@ def test_cli_progress_and_errors(tmp_path):
     assert r.returncode == 1 and "cannot open" in r.stderr
     r = subprocess.run([CLI, scene_file, "--bogus"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 2 and "usage" in r.stderr
+
+
+@pytest.mark.parametrize("split", ["samples", "tiles"])
+def test_cli_on_a_group_of_members(tmp_path, split):
+    """--devices: the same frames from a group (members sharing the one GPU of the test box). A byte may
+    differ from the single-GPU image only where a channel sits within 1e-7 of a quantisation step."""
+    scene_file = os.path.join(ROOT, "scenes", "spot.scene")
+    common = ["--width", "120", "--height", "80", "--spp", "6", "--its", "3", "--seed", "2"]
+    one, grp = tmp_path / "one.png", tmp_path / "grp.png"
+    r = subprocess.run([CLI, scene_file, "-o", str(one)] + common, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([CLI, scene_file, "-o", str(grp), "--devices", "0,0,0", "--split", split] + common, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stderr.count("member ") == 3
+    a, b = rt.load_png(one).astype(int), rt.load_png(grp).astype(int)
+    d = np.abs(a - b)
+    assert d.max() <= 1 and (d > 0).sum() <= 3
+    rays = [line.split(" rays in")[0].split()[-1] for line in r.stderr.splitlines() if "Mrays/s" in line]
+    r1 = subprocess.run([CLI, scene_file, "-o", str(one), "--devices", "0"] + common, capture_output=True, text=True, timeout=120)
+    assert r1.returncode == 0 and rays == [line.split(" rays in")[0].split()[-1] for line in r1.stderr.splitlines() if "Mrays/s" in line]
+    r = subprocess.run([CLI, scene_file, "--devices", "0,x"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "usage" in r.stderr

@@ -201,6 +201,22 @@ def test_device_calls_fail_loudly_without_gpu():
     with pytest.raises(_ffi.RtError):
         s.render(canvas, rt.render_params(width=8, height=8, spp=1))
     assert not canvas.any()
+    with pytest.raises(_ffi.RtError) as e:
+        rt.Group(s, [0, 1])
+    assert e.value.code == _ffi.RT_ERR_NO_DEVICE
+
+
+def test_group_arguments_are_checked_before_any_device_work():
+    s = scenes.build("sphere_floor")
+    for devices in ([], list(range(_ffi.RT_GROUP_MAX + 1))):
+        with pytest.raises(_ffi.RtError) as e:
+            rt.Group(s, devices)
+        assert e.value.code == _ffi.RT_ERR_INVALID and "members" in str(e.value)
+    import ctypes as C
+    n = C.c_uint32()
+    assert _ffi.lib.rt_group_size(None, C.byref(n)) == _ffi.RT_ERR_INVALID
+    assert _ffi.lib.rt_group_member_info(None, 0, None, None, None) == _ffi.RT_ERR_INVALID
+    _ffi.lib.rt_group_destroy(None)
 
 
 def test_tree_does_not_depend_on_builder_threads(monkeypatch):

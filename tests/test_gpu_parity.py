@@ -331,3 +331,36 @@ def test_full_size_properties(gpu_scenes):
     assert r1 + r2 == rays
     assert np.allclose(halves, a, rtol=1e-13, atol=1e-15)
     assert rays > w * h * 64 and np.isfinite(a).all() and a.min() >= 0.0
+
+
+def psnr(a, b, peak=1.0):
+    mse = float(np.mean((np.clip(a, 0, peak) - np.clip(b, 0, peak)) ** 2))
+    return np.inf if mse == 0.0 else 10.0 * np.log10(peak * peak / mse)
+
+
+@pytest.mark.parametrize("name,w,h", [("spot", 160, 120), ("sphere_floor", 160, 90)])
+def test_image_error_against_the_noise_floor(gpu_scenes, oracle, name, w, h):
+    """Image agreement in the units a renderer is judged in. Two independent seeds at the same
+    sample count differ by the Monte-Carlo noise (the floor any comparison of images has to live
+    with); the HIP image and the oracle's image of the SAME seed must differ by nothing like that.
+    Stated bound: RMSE(HIP, oracle) < 1e-12 (PSNR > 240 dB), against a floor of 20-35 dB."""
+    s, o = gpu_scenes(name), oracle.OracleScene.build(name)
+
+    def gpu(seed, spp):
+        c = np.zeros((h, w, 3))
+        s.render(c, rt.render_params(width=w, height=h, spp=spp, seed=seed))
+        return c
+
+    a16, b16 = gpu(11, 16), gpu(12, 16)
+    oc = np.zeros((h, w, 3))
+    o.render(oc, rt.render_params(width=w, height=h, spp=16, seed=11))
+    rmse_same = float(np.sqrt(np.mean((a16 - oc) ** 2)))
+    floor16 = float(np.sqrt(np.mean((a16 - b16) ** 2)))
+    print(f"{name}: RMSE HIP-oracle {rmse_same:.2e} ({psnr(a16, oc):.0f} dB); two seeds at 16 spp {floor16:.4f} ({psnr(a16, b16):.1f} dB)")
+    assert rmse_same < 1e-12 and psnr(a16, oc) > 240.0
+    assert 15.0 < psnr(a16, b16) < 45.0
+    # the floor is sampling noise and nothing else: it falls like 1/sqrt(spp), and the seeds agree in the mean
+    a64, b64 = gpu(11, 64), gpu(12, 64)
+    floor64 = float(np.sqrt(np.mean((a64 - b64) ** 2)))
+    assert 1.6 < floor16 / floor64 < 2.4, (floor16, floor64)
+    assert abs(a64.mean() - b64.mean()) < 4.0 * floor64 / np.sqrt(w * h)

@@ -27,6 +27,7 @@ WORKLOADS = {
     "ogre_4k_256spp": ("ogre", 3840, 2160, 256, "configs[2]"),
     "spot_4k_1024spp": ("spot", 3840, 2160, 1024, "configs[3]"),
     "spot_default_10spp": ("spot", 1600, 1200, 10, "configs[0]"),
+    "spot_20k_default_10spp": ("spot_20k", 1600, 1200, 10, "configs[0] with the 20000x20000 texture src/main.rs:1273 opens"),
     "spot_4k_256spp": ("spot", 3840, 2160, 256, "the sec/frame figure of BASELINE.json's metric"),
     "spot_grid14_8k_4spp": ("spot_grid:14x14", 7680, 4320, 4, "configs[4] (1 spp-block of it)"),
 }

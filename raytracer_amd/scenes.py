@@ -1,6 +1,9 @@
 """The reference's scenes, assembled through the C ABI exactly as src/main.rs assembles them.
 
-sphere_scene   src/main.rs:1270-1450   the default scene ("Spot": floor, cow, six spheres)
+sphere_scene   src/main.rs:1270-1450   the default scene ("Spot": floor, cow, six spheres); "spot"
+               takes the cow's texture from the 1024x1024 file its material library names,
+               "spot_20k" from the 20000x20000 rendering of the same picture that
+               src/main.rs:1273 opens (1.6 GB of texels once decoded)
 lens_scene     src/main.rs:1223-1268
 sphere_floor_scene / ogre_scene: the default scene's floor plus the objects that are present
 but commented out at src/main.rs:1353-1364 and 1434-1445 (benchmark configurations)
@@ -98,6 +101,7 @@ def spot_grid_scene(nx, nz, assets=ASSETS, spot_texture="spot_texture.png"):
 
 SCENES = {
     "spot": sphere_scene,
+    "spot_20k": lambda assets=ASSETS: sphere_scene(assets, "spot_texture_20k.png"),
     "lens": lens_scene,
     "sphere_floor": sphere_floor_scene,
     "ogre": ogre_scene,

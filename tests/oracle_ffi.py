@@ -83,6 +83,12 @@ class OracleScene:
     @staticmethod
     def build(name, assets=ASSETS, spot_texture="spot_texture.png"):
         register_default_textures()
+        if name == "spot_20k":  # the default scene with the 20000x20000 texture of src/main.rs:1273
+            name, spot_texture = "spot", "spot_texture_20k.png"
+            if spot_texture not in _registered:
+                from raytracer_amd.scenes import load_texture
+
+                register_texture(spot_texture, load_texture(os.path.join(assets, spot_texture)))
         return OracleScene(lib.orc_scene_build(name.encode(), assets.encode(), spot_texture.encode()))
 
     @staticmethod

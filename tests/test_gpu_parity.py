@@ -333,6 +333,26 @@ def test_full_size_properties(gpu_scenes):
     assert rays > w * h * 64 and np.isfinite(a).all() and a.min() >= 0.0
 
 
+def test_default_scene_with_its_20000_pixel_texture(oracle):
+    """The texture file the reference's default scene actually opens (src/main.rs:1273): 1.6 GB of
+    texels in HBM instead of 4 MB in cache. Same bars as every other render."""
+    s = scenes.build("spot_20k")
+    s.upload(0)
+    assert s.info().device_bytes > 1_600_000_000
+    o = oracle.OracleScene.build("spot_20k")
+    w, h, spp = 160, 120, 3
+    p = rt.render_params(width=w, height=h, spp=spp, seed=9)
+    c = np.zeros((h, w, 3)); oc = np.zeros((h, w, 3))
+    rays = s.render(c, p)
+    orays, _ = o.render(oc, p)
+    assert rays == orays and rel_err(c, oc) < IMG_RTOL
+    # not the small texture's image: the finer texels show
+    s1 = scenes.build("spot")
+    c1 = np.zeros((h, w, 3))
+    assert s1.render(c1, p) == rays  # texels colour paths, they never steer them
+    assert 1e-5 < np.abs(c1 - c).mean() < 0.02
+
+
 def psnr(a, b, peak=1.0):
     mse = float(np.mean((np.clip(a, 0, peak) - np.clip(b, 0, peak)) ** 2))
     return np.inf if mse == 0.0 else 10.0 * np.log10(peak * peak / mse)

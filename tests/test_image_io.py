@@ -25,6 +25,28 @@ def test_reference_textures_decode_like_pillow(rel):
     assert np.array_equal(got, want)
 
 
+def test_the_20000_pixel_texture_of_the_default_scene():
+    """src/main.rs:1273 opens spot_texture_20k.png: 20000 x 20000 RGBA, 1.6 GB once decoded — the
+    largest input the reference itself feeds this path."""
+    path = os.path.join(ASSETS, "spot_texture_20k.png")
+    got = rt.load_png(path)
+    assert got.shape == (20000, 20000, 4)
+    old = PIL.MAX_IMAGE_PIXELS
+    PIL.MAX_IMAGE_PIXELS = None  # Pillow's guard against huge images; this one is known
+    try:
+        with PIL.open(path) as im:
+            rgba = im.convert("RGBA")
+            want = np.asarray(rgba, dtype=np.uint8)
+            coarse = np.asarray(rgba.resize((500, 500), PIL.BOX), dtype=np.float64)
+    finally:
+        PIL.MAX_IMAGE_PIXELS = old
+    assert np.array_equal(got, want)
+    # the same picture as the 1024 x 1024 file, rendered finer: area means agree
+    with PIL.open(os.path.join(ASSETS, "spot_texture.png")) as im:
+        small = np.asarray(im.convert("RGBA").resize((500, 500), PIL.BOX), dtype=np.float64)
+    assert np.abs(coarse - small)[..., :3].mean() < 1.0
+
+
 @pytest.mark.parametrize("mode", ["L", "LA", "RGB", "RGBA", "P"])
 @pytest.mark.parametrize("size", [(1, 1), (7, 5), (64, 33)])
 def test_colour_types_and_filters(tmp_path, mode, size):

@@ -26,6 +26,10 @@ pub const RT_FLAG_NO_REGEN: u32 = 8;
 pub const RT_FLAG_MEGAKERNEL: u32 = 16;
 pub const RT_FLAG_PIPELINE: u32 = 32;
 
+pub const RT_BUILD_LBVH: u32 = 0;
+pub const RT_BUILD_PLOC: u32 = 1;
+pub const RT_BUILD_DEFAULT: u32 = RT_BUILD_PLOC;
+
 pub const RT_GROUP_MAX: u32 = 16;
 pub const RT_SPLIT_SAMPLES: u32 = 0;
 pub const RT_SPLIT_TILES: u32 = 1;
@@ -196,6 +200,7 @@ extern "C" {
     pub fn rt_device_count() -> c_int;
     pub fn rt_scene_upload(scene: *mut rt_scene, device: c_int) -> c_int;
     pub fn rt_scene_rebuild_on_device(scene: *mut rt_scene, device: c_int) -> c_int;
+    pub fn rt_scene_rebuild_on_device_with(scene: *mut rt_scene, device: c_int, method: u32) -> c_int;
     pub fn rt_trace(scene: *mut rt_scene, org3: *const f64, dir3: *const f64, n: usize, out: *mut rt_hit) -> c_int;
     pub fn rt_primary_hits(scene: *mut rt_scene, p: *const rt_render_params, obj: *mut i32, tri: *mut i32, t: *mut f64, u: *mut f64, v: *mut f64) -> c_int;
     pub fn rt_render_accumulate(scene: *mut rt_scene, p: *const rt_render_params, canvas: *mut f64, rays_out: *mut u64) -> c_int;

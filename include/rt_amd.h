@@ -275,13 +275,23 @@ int rt_device_count(void);
 int rt_scene_upload(rt_scene* scene, int device);
 
 /* Replaces the scene's tree (built on the host when the scene was created; BVH::build,
- * src/main.rs:771) by a linear BVH built on `device`: Morton codes, one radix sort, the
- * hierarchy and its boxes in a few kernels. Milliseconds instead of tenths of a second for a
- * million triangles, at the price of slower traversal: for scenes that change from frame to
- * frame. Hit records do not depend on the tree. The scene must be uploaded again afterwards
- * (the render calls do that themselves). RT_ERR_INVALID, with the host tree kept, if the linear
- * tree would be deeper than the traversal stack allows (62 levels). */
-int rt_scene_rebuild_on_device(rt_scene* scene, int device);
+ * src/main.rs:771) by one built on `device`, in milliseconds instead of tenths of a second for a
+ * million triangles, at the price of somewhat slower traversal: for scenes that change from
+ * frame to frame. Hit records do not depend on the tree. The scene must be uploaded again
+ * afterwards (the render calls do that themselves). RT_ERR_INVALID, with the host tree kept, if
+ * the new tree would be deeper than the traversal stack allows (62 levels).
+ * Two constructions, both starting from one radix sort of the triangles along the Morton curve:
+ *   RT_BUILD_PLOC  bottom-up clustering: every cluster looks a few places along the curve for
+ *                  the neighbour it would share the smallest box with, mutual choices merge,
+ *                  repeat until one is left; subtrees of up to four triangles become leaves where
+ *                  the surface-area cost says so. Traverses 6-16 % slower than the host's tree.
+ *   RT_BUILD_LBVH  the hierarchy implied by the Morton codes' common prefixes (Karras 2012):
+ *                  a fixed handful of launches, trees that traverse 30-95 % slower. */
+#define RT_BUILD_LBVH 0u
+#define RT_BUILD_PLOC 1u
+#define RT_BUILD_DEFAULT RT_BUILD_PLOC
+int rt_scene_rebuild_on_device(rt_scene* scene, int device); /* RT_BUILD_DEFAULT */
+int rt_scene_rebuild_on_device_with(rt_scene* scene, int device, uint32_t method);
 
 /* Batch Scene::hit, src/main.rs:776-814. org3/dir3 are [n][3]; dir need not be unit length. */
 int rt_trace(rt_scene* scene, const double* org3, const double* dir3, size_t n, rt_hit* out);

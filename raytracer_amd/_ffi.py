@@ -28,6 +28,10 @@ RT_FLAG_NO_REGEN = 8
 RT_FLAG_MEGAKERNEL = 16
 RT_FLAG_PIPELINE = 32
 
+RT_BUILD_LBVH = 0
+RT_BUILD_PLOC = 1
+RT_BUILD_DEFAULT = RT_BUILD_PLOC
+
 RT_GROUP_MAX = 16
 RT_SPLIT_SAMPLES = 0
 RT_SPLIT_TILES = 1
@@ -179,6 +183,7 @@ SIGNATURES = {
     "rt_scene_export_bvh": (C.c_int, [_P, _P, _P]),
     "rt_device_count": (C.c_int, []),
     "rt_scene_rebuild_on_device": (C.c_int, [_P, C.c_int]),
+    "rt_scene_rebuild_on_device_with": (C.c_int, [_P, C.c_int, C.c_uint32]),
     "rt_scene_upload": (C.c_int, [_P, C.c_int]),
     "rt_trace": (C.c_int, [_P, _P, _P, C.c_size_t, _P]),
     "rt_primary_hits": (C.c_int, [_P, C.POINTER(rt_render_params), _P, _P, _P, _P, _P]),

@@ -252,9 +252,14 @@ class Scene:
         return nodes, order
 
     # ---- device -----------------------------------------------------------------------
-    def rebuild_on_device(self, device=0):
-        """Replaces the host-built tree by a linear BVH built on the GPU (for scenes that change)."""
-        check(lib.rt_scene_rebuild_on_device(self._h, int(device)), "rt_scene_rebuild_on_device")
+    def rebuild_on_device(self, device=0, method=None):
+        """Replaces the host-built tree by one built on the GPU (for scenes that change):
+        method "lbvh" (Morton hierarchy), "ploc" (bottom-up clustering) or None for the default."""
+        if method is None:
+            check(lib.rt_scene_rebuild_on_device(self._h, int(device)), "rt_scene_rebuild_on_device")
+        else:
+            m = {"lbvh": _ffi.RT_BUILD_LBVH, "ploc": _ffi.RT_BUILD_PLOC}.get(method, method)
+            check(lib.rt_scene_rebuild_on_device_with(self._h, int(device), int(m)), "rt_scene_rebuild_on_device_with")
 
     def upload(self, device=0):
         check(lib.rt_scene_upload(self._h, int(device)), "rt_scene_upload")

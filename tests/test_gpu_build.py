@@ -14,13 +14,14 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+@pytest.mark.parametrize("method", ["lbvh", "ploc"])
 @pytest.mark.parametrize("name", ["spot", "sphere_floor", "ogre"])
-def test_device_built_tree_is_valid_and_changes_no_result(oracle, name):
+def test_device_built_tree_is_valid_and_changes_no_result(oracle, name, method):
     if rt.device_count() < 1:
         pytest.fail("no HIP device visible")
     host = scenes.build(name)
     dev = scenes.build(name)
-    dev.rebuild_on_device(0)
+    dev.rebuild_on_device(0, method)
     i = dev.info()
     assert i.n_triangles == host.info().n_triangles and 0 < i.bvh_nodes < i.n_triangles and i.bvh_depth <= 62
     nodes, order = dev.export_bvh()
@@ -66,9 +67,11 @@ def test_small_and_degenerate_inputs(oracle):
         "forty coincident triangles (equal Morton codes)": np.tile(one, (40, 1, 1)),
         "a line of equal centres and one far away": np.concatenate([np.tile(one, (9, 1, 1)), one[None] + 100.0]),
     }
-    for what, tv in cases.items():
+    cases["a regular grid (every neighbour ties)"] = np.array(
+        [[[x, y, -3.0], [x + 1, y, -3.0], [x, y + 1, -3.0]] for y in range(-8, 8) for x in range(-8, 8)], dtype=np.float64)
+    for (what, tv), method in [(c, m) for c in cases.items() for m in ("lbvh", "ploc")]:
         a, b = _scene(tv), _scene(tv)
-        b.rebuild_on_device(0)
+        b.rebuild_on_device(0, method)
         i = b.info()
         nodes, order = b.export_bvh()
         assert sorted(order.tolist()) == list(range(len(tv))), what
@@ -82,18 +85,21 @@ def test_small_and_degenerate_inputs(oracle):
     assert s.info().bvh_nodes == 0 and s.hit(co, cd).tobytes() == want
     with pytest.raises(rt.RtError, match="out of range"):
         s.rebuild_on_device(99)
+    with pytest.raises(rt.RtError, match="unknown method"):
+        s.rebuild_on_device(0, 7)
 
 
-def test_million_triangle_scene_builds_in_milliseconds():
+@pytest.mark.parametrize("method", ["lbvh", "ploc"])
+def test_million_triangle_scene_builds_in_milliseconds(method):
     s = scenes.build("spot_grid:14x14")
     t0 = time.perf_counter()
-    s.rebuild_on_device(0)
+    s.rebuild_on_device(0, method)
     first = time.perf_counter() - t0
     t0 = time.perf_counter()
-    s.rebuild_on_device(0)
+    s.rebuild_on_device(0, method)
     again = time.perf_counter() - t0
     i = s.info()
-    print(f"device build of {i.n_triangles} triangles: {first * 1e3:.1f} ms, again {again * 1e3:.1f} ms; "
+    print(f"{method} build of {i.n_triangles} triangles: {first * 1e3:.1f} ms, again {again * 1e3:.1f} ms; "
           f"{i.bvh_nodes} nodes, depth {i.bvh_depth}")
     assert i.bvh_depth <= 62 and again < 2.0
     p = rt.render_params(width=160, height=90, spp=1, seed=1)

@@ -19,11 +19,16 @@ ap.add_argument("--spp", type=int, default=64)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--forms", default="wave,mega,noregen")
 ap.add_argument("--count", action="store_true")
-ap.add_argument("--device-build", action="store_true", help="replace the host-built tree by the GPU-built linear BVH")
+ap.add_argument("--device-build", nargs="?", const="default", default=None, choices=["default", "lbvh", "ploc"],
+                help="replace the host-built tree by one built on the GPU")
 a = ap.parse_args()
 s = scenes.build(a.scene)
 if a.device_build:
-    s.rebuild_on_device(0)
+    import time as _t
+    for _ in range(2):
+        t0 = _t.perf_counter()
+        s.rebuild_on_device(0, None if a.device_build == "default" else a.device_build)
+        print(f"device build ({a.device_build}): {(_t.perf_counter() - t0) * 1e3:.1f} ms")
 s.upload(0)
 print(f"tree: {s.info().bvh_nodes} nodes, {s.info().bvh_leaves} leaves, depth {s.info().bvh_depth}")
 canvas = torch.zeros((a.height, a.width, 3), dtype=torch.float64, device="cuda")

@@ -285,6 +285,8 @@ int rt_scene_upload(rt_scene* scene, int device);
  *                  the neighbour it would share the smallest box with, mutual choices merge,
  *                  repeat until one is left; subtrees of up to four triangles become leaves where
  *                  the surface-area cost says so. Traverses 6-16 % slower than the host's tree.
+ *                  On a soup of triangles whose boxes all overlap the clusters chain up; if the
+ *                  tree gets too deep the call falls back to RT_BUILD_LBVH by itself.
  *   RT_BUILD_LBVH  the hierarchy implied by the Morton codes' common prefixes (Karras 2012):
  *                  a fixed handful of launches, trees that traverse 30-95 % slower. */
 #define RT_BUILD_LBVH 0u

@@ -414,11 +414,20 @@ struct DevMem {  // frees what a failed or finished build allocated
 }  // namespace
 
 static int rt_scene_rebuild_on_device_body(rt_scene* s, int device, uint32_t method);
+#define BUILD_TOO_DEEP 1 /* internal: the tree would overflow the traversal stack */
+// Clustering degenerates on triangle soups whose boxes all overlap (one cluster swallows its
+// neighbours one at a time and the tree becomes a chain); the Morton hierarchy cannot be deeper
+// than its 63 code bits plus the tie-break, so it takes over when that happens.
+static int rebuild_with_fallback(rt_scene* s, int device, uint32_t method) {
+  int rc = rt_scene_rebuild_on_device_body(s, device, method);
+  if (rc == BUILD_TOO_DEEP && method == RT_BUILD_PLOC) rc = rt_scene_rebuild_on_device_body(s, device, RT_BUILD_LBVH);
+  return rc == BUILD_TOO_DEEP ? RT_ERR_INVALID : rc;
+}
 extern "C" int rt_scene_rebuild_on_device(rt_scene* s, int device) {
-  return rt_guard("rt_scene_rebuild_on_device", [&] { return rt_scene_rebuild_on_device_body(s, device, RT_BUILD_DEFAULT); });
+  return rt_guard("rt_scene_rebuild_on_device", [&] { return rebuild_with_fallback(s, device, RT_BUILD_DEFAULT); });
 }
 extern "C" int rt_scene_rebuild_on_device_with(rt_scene* s, int device, uint32_t method) {
-  return rt_guard("rt_scene_rebuild_on_device", [&] { return rt_scene_rebuild_on_device_body(s, device, method); });
+  return rt_guard("rt_scene_rebuild_on_device", [&] { return rebuild_with_fallback(s, device, method); });
 }
 
 // The clustering rounds of the PLOC build, after the sort. Leaves the node pool (boxes, counts,
@@ -594,7 +603,7 @@ static int rt_scene_rebuild_on_device_body(rt_scene* s, int device, uint32_t met
     if (stats[1] > RT_BVH_MAX_DEPTH) {
       rt_set_error("rt_scene_rebuild_on_device: the clustered tree is %u levels deep (limit %d); the scene keeps its host-built tree",
                    stats[1], RT_BVH_MAX_DEPTH);
-      return RT_ERR_INVALID;
+      return BUILD_TOO_DEEP;
     }
     nodes.resize(n_kept);
     HIP_TRY_B(hipMemcpy(nodes.data(), d_nodes, (size_t)n_kept * sizeof(BvhNode), hipMemcpyDeviceToHost));
@@ -630,9 +639,9 @@ static int rt_scene_rebuild_on_device_body(rt_scene* s, int device, uint32_t met
     HIP_TRY_B(hipMemcpy(stats, d_stats, sizeof stats, hipMemcpyDeviceToHost));
     const size_t n_nodes = (size_t)last_slot + last_kept;
     if (stats[1] > RT_BVH_MAX_DEPTH) {
-      rt_set_error("rt_scene_rebuild_on_device: the linear tree is %u levels deep (limit %d); the scene keeps its host-built tree",
+      rt_set_error("rt_scene_rebuild_on_device: the Morton hierarchy is %u levels deep (limit %d); the scene keeps its host-built tree",
                    stats[1], RT_BVH_MAX_DEPTH);
-      return RT_ERR_INVALID;
+      return BUILD_TOO_DEEP;
     }
     nodes.resize(n_nodes);
     HIP_TRY_B(hipMemcpy(nodes.data(), d_nodes, n_nodes * sizeof(BvhNode), hipMemcpyDeviceToHost));

@@ -69,6 +69,8 @@ def test_small_and_degenerate_inputs(oracle):
     }
     cases["a regular grid (every neighbour ties)"] = np.array(
         [[[x, y, -3.0], [x + 1, y, -3.0], [x, y + 1, -3.0]] for y in range(-8, 8) for x in range(-8, 8)], dtype=np.float64)
+    # boxes that all overlap: clustering chains up here and hands over to the Morton hierarchy
+    cases["a soup of scene-sized triangles"] = rng.normal(size=(5000, 3, 3)) * 0.01 + np.array([0, 0, -3.0])
     for (what, tv), method in [(c, m) for c in cases.items() for m in ("lbvh", "ploc")]:
         a, b = _scene(tv), _scene(tv)
         b.rebuild_on_device(0, method)

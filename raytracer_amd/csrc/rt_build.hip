@@ -20,6 +20,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -506,6 +507,15 @@ static int rt_scene_rebuild_on_device_body(rt_scene* s, int device, uint32_t met
   const size_t n = s->tri_obj.size();
   if (n == 0) return RT_OK;  // spheres only: there is no tree
   HIP_TRY_B(hipSetDevice(device));
+  const bool timing = std::getenv("RT_BUILD_TIMING") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto phase = [&](const char* what) {
+    if (!timing) return;
+    (void)hipDeviceSynchronize();
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[rt device build] %-9s %.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
 
   // centre bounds of the triangle boxes, for the quantisation of the Morton codes
   double clo[3], chi[3];
@@ -531,6 +541,7 @@ static int rt_scene_rebuild_on_device_body(rt_scene* s, int device, uint32_t met
     scale[c] = ext > 0.0 && std::isfinite(ext) ? 2097152.0 / ext : 0.0;
   }
   const double pad = rt_scene_box_pad(s);
+  phase("bounds");
 
   DevMem mem;
   int rc;
@@ -551,6 +562,7 @@ static int rt_scene_rebuild_on_device_body(rt_scene* s, int device, uint32_t met
       (rc = mem.get(&d_nodes, ni)))
     return rc;
   HIP_TRY_B(hipMemcpy(d_verts, s->tri_vertices.data(), n * 9 * sizeof(double), hipMemcpyHostToDevice));
+  phase("copy in");
   const uint32_t grid_n = (uint32_t)((n + BUILD_BLOCK - 1) / BUILD_BLOCK);
   hipLaunchKernelGGL(k_boxes_codes, dim3(grid_n), dim3(BUILD_BLOCK), 0, nullptr, d_verts, (uint32_t)n, clo[0], clo[1], clo[2], scale[0],
                      scale[1], scale[2], d_tri_boxes, d_keys, d_vals);
@@ -563,6 +575,7 @@ static int rt_scene_rebuild_on_device_body(rt_scene* s, int device, uint32_t met
   if ((rc = mem.get(&d_tmp, tmp_bytes))) return rc;
   HIP_TRY_B(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_keys, d_keys_sorted, d_vals, d_vals_sorted, (int)n, 0, 63, nullptr));
 
+  phase("sort");
   std::vector<int32_t> leaf_order(n);
   std::vector<BvhNode> nodes;
   int32_t root_ref;
@@ -650,6 +663,7 @@ static int rt_scene_rebuild_on_device_body(rt_scene* s, int device, uint32_t met
     leaves = stats[0];
   }
   HIP_TRY_B(hipMemcpy(leaf_order.data(), order_on_device ? d_leaf_order : d_vals_sorted, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  phase("tree");
 
   // the scene takes the new tree; its device copy, if any, is stale
   if (s->dev) {
@@ -662,5 +676,6 @@ static int rt_scene_rebuild_on_device_body(rt_scene* s, int device, uint32_t met
   s->bvh_depth = depth;
   s->bvh_leaves = leaves;
   rt_fill_leaf_records(s);
+  phase("records");
   return RT_OK;
 }

@@ -357,38 +357,71 @@ static int rt_objects_push_sphere_body(rt_objects* objs, const double centre[3],
 }
 
 // Triangle records in leaf order (rt_types.h), from the flat arrays and s->leaf_order.
+// Threads the host's scene passes may use: RT_BUILD_THREADS, else min(16, cores).
+unsigned rt_build_threads() {
+  unsigned threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  if (const char* e = std::getenv("RT_BUILD_THREADS")) threads = (unsigned)std::max(1, std::atoi(e));
+  return threads;
+}
+
+// body(piece, begin, end) over [0, n) in at most 64 contiguous pieces, one per thread. The pieces
+// write disjoint outputs, so the result does not depend on the number of threads.
+template <class F>
+static void parallel_ranges(size_t n, size_t min_per_thread, F&& body) {
+  const size_t threads =
+      std::max<size_t>(1, std::min<size_t>(std::min<size_t>(64, rt_build_threads()), n / std::max<size_t>(1, min_per_thread)));
+  if (threads <= 1) {
+    body((size_t)0, (size_t)0, n);
+    return;
+  }
+  std::vector<std::thread> pool;
+  pool.reserve(threads - 1);
+  for (size_t k = 1; k < threads; ++k) pool.emplace_back([&, k] { body(k, n * k / threads, n * (k + 1) / threads); });
+  body((size_t)0, (size_t)0, n / threads);
+  for (std::thread& t : pool) t.join();
+}
+
 void rt_fill_leaf_records(rt_scene* s) {
   const size_t n = s->leaf_order.size();
   s->tri_geom.resize(n);
   s->tri_shade.resize(n);
-  for (size_t slot = 0; slot < n; ++slot) {
-    const size_t t = (size_t)s->leaf_order[slot];
-    TriGeom& g = s->tri_geom[slot];
-    const double* v = &s->tri_vertices[t * 9];
-    for (int c = 0; c < 3; ++c) {
-      g.a[c] = v[c];
-      g.ab[c] = v[3 + c] - v[c];  // src/main.rs:188
-      g.ac[c] = v[6 + c] - v[c];  // src/main.rs:189
+  parallel_ranges(n, 16384, [s](size_t, size_t begin, size_t end) {
+    for (size_t slot = begin; slot < end; ++slot) {
+      const size_t t = (size_t)s->leaf_order[slot];
+      TriGeom& g = s->tri_geom[slot];
+      const double* v = &s->tri_vertices[t * 9];
+      for (int c = 0; c < 3; ++c) {
+        g.a[c] = v[c];
+        g.ab[c] = v[3 + c] - v[c];  // src/main.rs:188
+        g.ac[c] = v[6 + c] - v[c];  // src/main.rs:189
+      }
+      g.flat = (int32_t)t;
+      g.obj = s->tri_obj[t];
+      TriShade& sh = s->tri_shade[slot];
+      for (int k = 0; k < 3; ++k) {
+        for (int c = 0; c < 3; ++c) sh.n[k][c] = s->tri_normals[t * 9 + k * 3 + c];
+        for (int c = 0; c < 2; ++c) sh.uv[k][c] = s->tri_uvs[t * 6 + k * 2 + c];
+      }
+      sh.tri = s->tri_idx[t];
+      sh.obj = s->tri_obj[t];
     }
-    g.flat = (int32_t)t;
-    g.obj = s->tri_obj[t];
-    TriShade& sh = s->tri_shade[slot];
-    for (int k = 0; k < 3; ++k) {
-      for (int c = 0; c < 3; ++c) sh.n[k][c] = s->tri_normals[t * 9 + k * 3 + c];
-      for (int c = 0; c < 2; ++c) sh.uv[k][c] = s->tri_uvs[t * 6 + k * 2 + c];
-    }
-    sh.tri = s->tri_idx[t];
-    sh.obj = s->tri_obj[t];
-  }
+  });
 }
 
 // Absolute padding of every child box: 2^-20 of the largest finite coordinate in the scene (at
 // least 2^-20). It covers the rounding slop of the binary64 triangle test (a hit accepted a hair
 // outside the exact triangle) with five orders of magnitude to spare for well-conditioned hits.
 double rt_scene_box_pad(const rt_scene* s) {
+  const std::vector<double>& v = s->tri_vertices;
+  std::vector<double> part(64, 1.0);  // a maximum: the same whatever the pieces
+  parallel_ranges(v.size(), 1u << 20, [&](size_t piece, size_t begin, size_t end) {
+    double extent = 1.0;
+    for (size_t i = begin; i < end; ++i)
+      if (std::isfinite(v[i])) extent = std::max(extent, std::fabs(v[i]));
+    part[piece] = extent;
+  });
   double extent = 1.0;
-  for (double x : s->tri_vertices)
-    if (std::isfinite(x)) extent = std::max(extent, std::fabs(x));
+  for (double x : part) extent = std::max(extent, x);
   return extent * 9.5367431640625e-07;
 }
 
@@ -655,8 +688,7 @@ int build_scene_accel(rt_scene* s) {
   Builder b{tb, cen, s->leaf_order, scratch, pad};
   int fork_levels = 0;  // 2^fork_levels subtree builds run at once; RT_BUILD_THREADS caps it
   {
-    unsigned threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-    if (const char* e = std::getenv("RT_BUILD_THREADS")) threads = (unsigned)std::max(1, std::atoi(e));
+    const unsigned threads = rt_build_threads();
     while ((2u << fork_levels) <= threads && fork_levels < 6) ++fork_levels;
   }
   lap("boxes");

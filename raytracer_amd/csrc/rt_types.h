@@ -124,6 +124,7 @@ static inline int rt_guard(const char* who, F&& body) noexcept {
 }
 void rt_fill_leaf_records(rt_scene* s);
 double rt_scene_box_pad(const rt_scene* s);
+unsigned rt_build_threads();
 // rt_device.hip
 void rt_device_scene_free(DeviceScene* d);
 int rt_device_scene_upload_from(const rt_scene* host, rt_scene* target, int device);

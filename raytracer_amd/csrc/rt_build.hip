@@ -9,7 +9,7 @@
 //     k-d trees", 2012) with a bottom-up pass for the boxes,
 // and a last pass that writes nodes in the library's own format (rt_types.h: two child boxes per
 // 64-byte node, leaves of 1..RT_LEAF_MAX triangles). Either takes milliseconds where the host's
-// binned-SAH builder takes tenths of a second; the clustered tree traverses 6-16 % slower than
+// binned-SAH builder takes tenths of a second; the clustered tree traverses 4-15 % slower than
 // the host's, the Morton hierarchy 30-95 % slower.
 //
 // The nearest hit does not depend on the tree (every box contains its triangles: exact binary64
@@ -289,7 +289,7 @@ __global__ void k_ploc_apply(uint32_t m, uint32_t base, const uint32_t* __restri
                              const unsigned long long* __restrict__ scan, const uint32_t* __restrict__ cluster,
                              uint32_t* __restrict__ cluster_out, Box6* __restrict__ nbox, uint32_t* __restrict__ ncount,
                              uint32_t* __restrict__ nparent, int2* __restrict__ nchild, double* __restrict__ ncost,
-                             uint32_t* __restrict__ nleaf, uint32_t n) {
+                             uint32_t* __restrict__ nleaf, uint32_t* __restrict__ nnodes, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
   const unsigned long long f = flags[i], sc = scan[i];
@@ -310,6 +310,8 @@ __global__ void k_ploc_apply(uint32_t m, uint32_t base, const uint32_t* __restri
     const bool leaf = count <= RT_LEAF_MAX && as_leaf <= as_tree;
     ncost[node] = leaf ? as_leaf : as_tree;
     nleaf[node - n] = leaf ? 1u : 0u;
+    // tree nodes in this subtree (none below a leaf), for the depth-first numbering
+    nnodes[node - n] = leaf ? 0u : 1u + (id >= n ? nnodes[id - n] : 0u) + (other >= n ? nnodes[other - n] : 0u);
     nparent[node] = PLOC_NONE;
     nchild[node - n] = make_int2((int)id, (int)other);
     nparent[id] = node << 1;
@@ -356,13 +358,32 @@ __global__ void k_ploc_mark(uint32_t ni, uint32_t n, const uint32_t* __restrict_
   kept[k] = keep;
 }
 
-// Kept nodes are written in reverse order of creation: the root is node 0 and the top of the
-// tree lies together at the front of the array.
-__global__ void k_ploc_emit(uint32_t ni, uint32_t n, uint32_t n_kept, const uint32_t* __restrict__ kept, const uint32_t* __restrict__ pos,
-                            const int2* __restrict__ nchild, const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nparent,
+// Preorder index of a kept node: one for every ancestor passed on the way up, plus the tree nodes
+// of every left sibling's subtree. The root is node 0, a node's left subtree follows it directly.
+__device__ __forceinline__ uint32_t ploc_node_slot(uint32_t node, uint32_t n, const uint32_t* __restrict__ nparent,
+                                                   const int2* __restrict__ nchild, const uint32_t* __restrict__ nnodes, uint32_t* depth_out) {
+  uint32_t slot = 0, depth = 0;
+  for (uint32_t p = nparent[node]; p != PLOC_NONE; p = nparent[node]) {
+    const uint32_t parent = p >> 1;
+    slot += 1u;
+    if (p & 1u) {
+      const uint32_t left = (uint32_t)nchild[parent - n].x;
+      if (left >= n) slot += nnodes[left - n];
+    }
+    node = parent;
+    depth++;
+  }
+  if (depth_out) *depth_out = depth;
+  return slot;
+}
+
+__global__ void k_ploc_emit(uint32_t ni, uint32_t n, const uint32_t* __restrict__ kept, const int2* __restrict__ nchild,
+                            const uint32_t* __restrict__ ncount, const uint32_t* __restrict__ nparent, const uint32_t* __restrict__ nnodes,
                             const Box6* __restrict__ nbox, double pad, BvhNode* __restrict__ out, unsigned int* __restrict__ stats) {
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= ni || !kept[k]) return;
+  uint32_t depth = 0;
+  const uint32_t slot = ploc_node_slot(n + k, n, nparent, nchild, nnodes, &depth);
   BvhNode nd = {};
   const int2 ch = nchild[k];
   unsigned int leaves = 0;
@@ -371,7 +392,8 @@ __global__ void k_ploc_emit(uint32_t ni, uint32_t n, uint32_t n_kept, const uint
     const Box6 b = nbox[r];
     int32_t ref;
     if (r >= n && kept[r - n]) {
-      ref = (int32_t)(n_kept - 1u - pos[r - n]);
+      const uint32_t left = (uint32_t)ch.x;
+      ref = (int32_t)(slot + 1u + (c && left >= n ? nnodes[left - n] : 0u));
     } else {
       const uint32_t first = ploc_first_slot(r, n, nparent, nchild, ncount, nullptr);
       ref = ~(int32_t)(first * RT_LEAF_MAX + (ncount[r] - 1u));
@@ -385,10 +407,8 @@ __global__ void k_ploc_emit(uint32_t ni, uint32_t n, uint32_t n_kept, const uint
     nd.bz[c * 2 + 1] = __double2float_ru(b.hi[2] + pad);
     nd.child[c] = ref;
   }
-  out[n_kept - 1u - pos[k]] = nd;
+  out[slot] = nd;
   if (leaves) {
-    uint32_t depth = 0;
-    (void)ploc_first_slot(n + k, n, nparent, nchild, ncount, &depth);
     atomicAdd(&stats[0], leaves);
     atomicMax(&stats[1], depth + 1u);  // interior nodes above the leaf: this node and its ancestors
   }
@@ -434,7 +454,7 @@ extern "C" int rt_scene_rebuild_on_device_with(rt_scene* s, int device, uint32_t
 // The clustering rounds of the PLOC build, after the sort. Leaves the node pool (boxes, counts,
 // parents, children) filled and returns the number of merged nodes in *n_merged (n - 1).
 static int ploc_rounds(DevMem& mem, uint32_t n, const uint32_t* d_vals_sorted, const Box6* d_tri_boxes, Box6* d_nbox, uint32_t* d_ncount,
-                       uint32_t* d_nparent, int2* d_nchild, uint32_t* d_nleaf, uint32_t* rounds_out) {
+                       uint32_t* d_nparent, int2* d_nchild, uint32_t* d_nleaf, uint32_t* d_nnodes, uint32_t* rounds_out) {
   int rc;
   uint32_t *d_cluster[2], *d_nn;
   double* d_ncost;
@@ -462,7 +482,7 @@ static int ploc_rounds(DevMem& mem, uint32_t n, const uint32_t* d_vals_sorted, c
     size_t bytes = scan_bytes;
     HIP_TRY_B(hipcub::DeviceScan::ExclusiveSum(d_tmp, bytes, d_flags, d_scan, (int)m, nullptr));
     hipLaunchKernelGGL(k_ploc_apply, grid, dim3(BUILD_BLOCK), 0, nullptr, m, base, d_nn, d_flags, d_scan, d_cluster[cur], d_cluster[cur ^ 1],
-                       d_nbox, d_ncount, d_nparent, d_nchild, d_ncost, d_nleaf, n);
+                       d_nbox, d_ncount, d_nparent, d_nchild, d_ncost, d_nleaf, d_nnodes, n);
     HIP_TRY_B(hipGetLastError());
     unsigned long long last_flag = 0, last_scan = 0;
     HIP_TRY_B(hipMemcpy(&last_flag, d_flags + (m - 1), sizeof last_flag, hipMemcpyDeviceToHost));
@@ -586,28 +606,25 @@ static int rt_scene_rebuild_on_device_body(rt_scene* s, int device, uint32_t met
     root_ref = ~(int32_t)(0u * RT_LEAF_MAX + (uint32_t)(n - 1));  // the whole scene is one leaf
   } else if (method == RT_BUILD_PLOC) {
     Box6* d_nbox;
-    uint32_t *d_ncount, *d_nparent, *d_nleaf;
+    uint32_t *d_ncount, *d_nparent, *d_nleaf, *d_nnodes;
     if ((rc = mem.get(&d_nbox, 2 * n - 1)) || (rc = mem.get(&d_ncount, 2 * n - 1)) || (rc = mem.get(&d_nparent, 2 * n - 1)) ||
-        (rc = mem.get(&d_leaf_order, n)) || (rc = mem.get(&d_nleaf, ni)))
+        (rc = mem.get(&d_leaf_order, n)) || (rc = mem.get(&d_nleaf, ni)) || (rc = mem.get(&d_nnodes, ni)))
       return rc;
     uint32_t rounds = 0;
-    if ((rc = ploc_rounds(mem, (uint32_t)n, d_vals_sorted, d_tri_boxes, d_nbox, d_ncount, d_nparent, d_child, d_nleaf, &rounds)) != RT_OK)
+    if ((rc = ploc_rounds(mem, (uint32_t)n, d_vals_sorted, d_tri_boxes, d_nbox, d_ncount, d_nparent, d_child, d_nleaf, d_nnodes, &rounds)) != RT_OK)
       return rc;
     const uint32_t grid_i = (uint32_t)((ni + BUILD_BLOCK - 1) / BUILD_BLOCK);
     hipLaunchKernelGGL(k_ploc_mark, dim3(grid_i), dim3(BUILD_BLOCK), 0, nullptr, (uint32_t)ni, (uint32_t)n, d_ncount, d_nleaf, d_nparent, d_kept);
     HIP_TRY_B(hipGetLastError());
-    size_t scan_bytes = 0;
-    HIP_TRY_B(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_kept, d_slot, (int)ni, nullptr));
-    char* d_scan;
-    if ((rc = mem.get(&d_scan, scan_bytes))) return rc;
-    HIP_TRY_B(hipcub::DeviceScan::ExclusiveSum(d_scan, scan_bytes, d_kept, d_slot, (int)ni, nullptr));
-    uint32_t last_kept = 0, last_slot = 0;
-    HIP_TRY_B(hipMemcpy(&last_kept, d_kept + (ni - 1), sizeof last_kept, hipMemcpyDeviceToHost));
-    HIP_TRY_B(hipMemcpy(&last_slot, d_slot + (ni - 1), sizeof last_slot, hipMemcpyDeviceToHost));
-    const uint32_t n_kept = last_slot + last_kept;  // the root (last, more than RT_LEAF_MAX triangles) is kept
+    uint32_t n_kept = 0;  // tree nodes under the root (the last merged node, never a leaf: more than RT_LEAF_MAX triangles)
+    HIP_TRY_B(hipMemcpy(&n_kept, d_nnodes + (ni - 1), sizeof n_kept, hipMemcpyDeviceToHost));
+    if (n_kept == 0 || n_kept > ni) {
+      rt_set_error("rt_scene_rebuild_on_device: internal error: %u tree nodes for %zu triangles", n_kept, n);
+      return RT_ERR_HIP;
+    }
     HIP_TRY_B(hipMemsetAsync(d_stats, 0, 2 * sizeof(unsigned int), nullptr));
-    hipLaunchKernelGGL(k_ploc_emit, dim3(grid_i), dim3(BUILD_BLOCK), 0, nullptr, (uint32_t)ni, (uint32_t)n, n_kept, d_kept, d_slot, d_child,
-                       d_ncount, d_nparent, d_nbox, pad, d_nodes, d_stats);
+    hipLaunchKernelGGL(k_ploc_emit, dim3(grid_i), dim3(BUILD_BLOCK), 0, nullptr, (uint32_t)ni, (uint32_t)n, d_kept, d_child, d_ncount, d_nparent,
+                       d_nnodes, d_nbox, pad, d_nodes, d_stats);
     hipLaunchKernelGGL(k_ploc_order, dim3(grid_n), dim3(BUILD_BLOCK), 0, nullptr, (uint32_t)n, d_vals_sorted, d_nparent, d_child, d_ncount,
                        d_leaf_order);
     HIP_TRY_B(hipGetLastError());

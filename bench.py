@@ -50,9 +50,11 @@ def main():
     ap.add_argument("--workload", default="sphere_floor_1080p_64spp", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-spp", type=int, default=0, help="spp of the CPU baseline sample (0 = auto)")
-    ap.add_argument("--split", default="samples", choices=["samples", "tiles"],
+    ap.add_argument("--split", default="samples", choices=["samples", "tiles", "samples_strong"],
                     help="N > 1: 'samples' = every rank renders the frame with its own samples (weak scaling, the default); "
-                         "'tiles' = the frame's 64x64 tiles are dealt round-robin over the ranks (strong scaling)")
+                         "'tiles' = the frame's 64x64 tiles are dealt round-robin over the ranks (strong scaling); "
+                         "'samples_strong' = the frame's samples are divided over the ranks (strong scaling: 1024 spp "
+                         "as 512/256/128 per GPU on 2/4/8 GPUs)")
     ap.add_argument("--form", default="wave", choices=["wave", "mega", "noregen"], help="scheduling form (A/B); default wavefront")
     args = ap.parse_args()
 
@@ -89,11 +91,18 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     base_flags = {"wave": 0, "mega": _ffi.RT_FLAG_MEGAKERNEL, "noregen": _ffi.RT_FLAG_NO_REGEN}[args.form]
 
+    strong = world > 1 and args.split in ("tiles", "samples_strong")
+
     def frame_params(step, flags):
-        p = rt.render_params(width=W, height=H, spp=spp, first_sample=step * spp * world, seed=0, flags=flags | base_flags)
+        first = step * spp * (1 if strong else world)  # every frame takes fresh samples of each pixel's stream
+        p = rt.render_params(width=W, height=H, spp=spp, first_sample=first, seed=0, flags=flags | base_flags)
         if world == 1:
             return p
-        return parallel.shard_tiles(p, rank, world, 64) if args.split == "tiles" else parallel.weak_samples(p, rank, world)
+        if args.split == "tiles":
+            return parallel.shard_tiles(p, rank, world, 64)
+        if args.split == "samples_strong":
+            return parallel.shard_samples(p, rank, world)
+        return parallel.weak_samples(p, rank, world)
 
     canvas = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda") if world == 1 else None
     # N > 1: two sum buffers, so that the all-reduce of one frame runs (on the collective's own
@@ -242,7 +251,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "strong" if (world > 1 and args.split == "tiles") else "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "reference scene files (assets/), counter-based sampling seed 0",
@@ -255,6 +264,8 @@ def main():
                 "sharding": "none" if world == 1 else (
                     f"tiles: 64x64 tiles dealt round-robin over {world} ranks at {spp} spp, disjoint pixels combined by one RCCL all-reduce(sum, fp32, {W * H * 3 * 4 / 1e6:.1f} MB) per frame"
                     if args.split == "tiles" else
+                    f"samples: {spp} spp divided over {world} ranks, one RCCL all-reduce(sum, fp32, {W * H * 3 * 4 / 1e6:.1f} MB) per frame"
+                    if args.split == "samples_strong" else
                     f"samples: {world} x {spp} spp, one RCCL all-reduce(sum, fp32, {W * H * 3 * 4 / 1e6:.1f} MB) per frame"),
                 "form": FORM_NAMES[args.form],
             },

@@ -384,3 +384,36 @@ def test_image_error_against_the_noise_floor(gpu_scenes, oracle, name, w, h):
     floor64 = float(np.sqrt(np.mean((a64 - b64) ** 2)))
     assert 1.6 < floor16 / floor64 < 2.4, (floor16, floor64)
     assert abs(a64.mean() - b64.mean()) < 4.0 * floor64 / np.sqrt(w * h)
+
+
+@pytest.mark.parametrize("name,w,h,spp", [("ogre", 3840, 2160, 256), ("spot", 3840, 2160, 1024)])
+def test_full_size_sample_additivity(gpu_scenes, name, w, h, spp):
+    """BASELINE configurations 3 and 4 at full size (4K, 256 and 1024 spp; the calls run in several
+    sample chunks with overlapped tails): a frame equals the sum of two calls that take half of its
+    sample stream each — what the sample split over GPUs relies on — and the ray counts add up."""
+    s = gpu_scenes(name)
+    whole = np.zeros((h, w, 3))
+    rays = s.render(whole, rt.render_params(width=w, height=h, spp=spp, seed=0))
+    halves = np.zeros((h, w, 3))
+    r1 = s.render(halves, rt.render_params(width=w, height=h, spp=spp // 2, first_sample=0, spp_total=spp, seed=0))
+    r2 = s.render(halves, rt.render_params(width=w, height=h, spp=spp // 2, first_sample=spp // 2, spp_total=spp, seed=0))
+    assert r1 + r2 == rays and rays > w * h * spp
+    assert np.allclose(halves, whole, rtol=1e-13, atol=1e-15)
+    assert np.isfinite(whole).all() and whole.min() >= 0.0 and 0.2 < whole.mean() < 2.0
+
+
+def test_full_size_tile_union(gpu_scenes):
+    """BASELINE configuration 5 at full size (1.15 M triangles, 7680x4320): the interleaved 64x64
+    tiles of eight ranks are disjoint and their union is the whole frame, bit for bit."""
+    s = gpu_scenes("spot_grid:14x14")
+    w, h, spp = 7680, 4320, 1
+    whole = np.zeros((h, w, 3))
+    rays = s.render(whole, rt.render_params(width=w, height=h, spp=spp, seed=0))
+    union = np.zeros((h, w, 3))
+    parts = 0
+    for r in range(8):
+        before = np.count_nonzero(union.any(axis=2))
+        parts += s.render(union, rt.render_params(width=w, height=h, spp=spp, seed=0, tile_size=64, tile_rank=r, tile_ranks=8))
+        assert np.count_nonzero(union.any(axis=2)) - before > w * h // 10  # every rank owns about an eighth
+    assert parts == rays
+    assert sha(union) == sha(whole)

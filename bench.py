@@ -235,11 +235,28 @@ def main():
             for k, v in sorted(timed.items())
         ]
         ms_resolve = [timed.get(4, [0.0, 1, 0])[0] / max(1, timed.get(4, [0.0, 1, 0])[1])]
+        # Counter-derived figures of the dominant kernel come from the committed rocprofv3 PMC
+        # passes of this same command (profiles/hbm_traffic.json); durations are measured live.
         traffic = None
+        valu_issue = None
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get(args.workload, {}).get(names[dom].split(" ")[0], {}).get("bytes_per_launch")
+                pmc = json.load(open(tfile)).get(args.workload, {}).get(names[dom].split(" ")[0], {})
+                traffic = pmc.get("bytes_per_launch")
+                if pmc.get("valu_wave_insts_per_launch"):
+                    prop = torch.cuda.get_device_properties(device)
+                    simds = 4 * prop.multi_processor_count
+                    clock_ghz = (getattr(prop, "clock_rate", 0) or 0) / 1e6  # kHz -> GHz
+                    if not (1.0 < clock_ghz <= 2.4):
+                        clock_ghz = 2.4  # the MI355X's peak engine clock
+                    peak = simds * clock_ghz / 4.0  # a SIMD issues one wave64 VALU instruction per 4 cycles
+                    ach = pmc["valu_wave_insts_per_launch"] / (launch_ms * 1e-3) / 1e9
+                    valu_issue = {"achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instructions/s",
+                                  "frac": round(ach / peak, 4), "lane_use": pmc.get("valu_lane_use"),
+                                  "note": "SQ_INSTS_VALU per launch (rocprofv3 PMC pass of this command, profiles/) over the live launch "
+                                          "duration, against 4 SIMDs x CUs x clock / 4; lane_use = share of the 64 lanes active per "
+                                          "VALU instruction"}
             except Exception:
                 traffic = None
         out = {
@@ -289,7 +306,8 @@ def main():
                 "resolve_ms": round(float(np.mean(ms_resolve)), 4),
                 "note": "achieved counts the algorithmic bytes of every node visit and triangle test; this scene's tree and triangles "
                         "stay in cache, so a fraction above what HBM could deliver means the kernel is not HBM bound (traffic = measured "
-                        "HBM bytes per launch); its VALU issue rate is what limits it",
+                        "HBM bytes per launch); its VALU issue rate is what limits it (valu_issue)",
+                "valu_issue": valu_issue,
                 "valu": {
                     "achieved_tflops": round(flops_per_ray * rays_per_launch / (launch_ms * 1e-3) / 1e12, 4),
                     "flops_per_ray": round(flops_per_ray, 1),

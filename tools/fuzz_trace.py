@@ -37,7 +37,7 @@ for k in range(cases):
             spheres, list(range(1, n_sph + 1)))
     host = rt.Scene.from_desc(*args)
     dev = rt.Scene.from_desc(*args)
-    dev.rebuild_on_device(0)
+    dev.rebuild_on_device(0, ("ploc", "lbvh")[k % 2])  # both device builders take turns
     o = orc.OracleScene.from_desc_arrays(*args)
     m = 4000
     org = rng.normal(size=(m, 3)) * scale * 3.0

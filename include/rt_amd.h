@@ -284,11 +284,11 @@ int rt_scene_upload(rt_scene* scene, int device);
  *   RT_BUILD_PLOC  bottom-up clustering: every cluster looks a few places along the curve for
  *                  the neighbour it would share the smallest box with, mutual choices merge,
  *                  repeat until one is left; subtrees of up to four triangles become leaves where
- *                  the surface-area cost says so. Traverses 4-15 % slower than the host's tree.
+ *                  the surface-area cost says so. Traverses 6-17 % slower than the host's tree.
  *                  On a soup of triangles whose boxes all overlap the clusters chain up; if the
  *                  tree gets too deep the call falls back to RT_BUILD_LBVH by itself.
  *   RT_BUILD_LBVH  the hierarchy implied by the Morton codes' common prefixes (Karras 2012):
- *                  a fixed handful of launches, trees that traverse 30-95 % slower. */
+ *                  a fixed handful of launches, trees that traverse 12-27 % slower. */
 #define RT_BUILD_LBVH 0u
 #define RT_BUILD_PLOC 1u
 #define RT_BUILD_DEFAULT RT_BUILD_PLOC

@@ -9,8 +9,8 @@
 //     k-d trees", 2012) with a bottom-up pass for the boxes,
 // and a last pass that writes nodes in the library's own format (rt_types.h: two child boxes per
 // 64-byte node, leaves of 1..RT_LEAF_MAX triangles). Either takes milliseconds where the host's
-// binned-SAH builder takes tenths of a second; the clustered tree traverses 4-15 % slower than
-// the host's, the Morton hierarchy 30-95 % slower.
+// binned-SAH builder takes tenths of a second; the clustered tree traverses 6-17 % slower than
+// the host's, the Morton hierarchy 12-27 % slower.
 //
 // The nearest hit does not depend on the tree (every box contains its triangles: exact binary64
 // minima and maxima, rounded outward to binary32 and padded exactly as the host builder does),
@@ -554,12 +554,17 @@ static int rt_scene_rebuild_on_device_body(rt_scene* s, int device, uint32_t met
       }
     }
   }
-  double scale[3];
+  // One scale for the three axes: the cells of the Morton grid are cubes, so neighbours along the
+  // curve are neighbours in space whatever the proportions of the scene (a field of meshes 40 times
+  // wider than tall, quantised per axis, would be sliced into sheets first).
+  double ext_max = 0.0;
   for (int c = 0; c < 3; ++c) {
     if (!(chi[c] >= clo[c])) clo[c] = chi[c] = 0.0;
     const double ext = chi[c] - clo[c];
-    scale[c] = ext > 0.0 && std::isfinite(ext) ? 2097152.0 / ext : 0.0;
+    if (std::isfinite(ext)) ext_max = std::max(ext_max, ext);
   }
+  double scale[3];
+  for (int c = 0; c < 3; ++c) scale[c] = ext_max > 0.0 ? 2097152.0 / ext_max : 0.0;
   const double pad = rt_scene_box_pad(s);
   phase("bounds");
 

@@ -26,6 +26,9 @@ pub const RT_FLAG_NO_REGEN: u32 = 8;
 pub const RT_FLAG_MEGAKERNEL: u32 = 16;
 pub const RT_FLAG_PIPELINE: u32 = 32;
 
+pub const RT_TREE_HOST: u32 = 0;
+pub const RT_TREE_NONE: u32 = 1;
+
 pub const RT_BUILD_LBVH: u32 = 0;
 pub const RT_BUILD_PLOC: u32 = 1;
 pub const RT_BUILD_DEFAULT: u32 = RT_BUILD_PLOC;
@@ -190,6 +193,8 @@ extern "C" {
 
     pub fn rt_scene_from_objects(objs: *const rt_objects, out: *mut *mut rt_scene) -> c_int;
     pub fn rt_scene_create(desc: *const rt_scene_desc, out: *mut *mut rt_scene) -> c_int;
+    pub fn rt_scene_from_objects_with(objs: *const rt_objects, tree: u32, out: *mut *mut rt_scene) -> c_int;
+    pub fn rt_scene_create_with(desc: *const rt_scene_desc, tree: u32, out: *mut *mut rt_scene) -> c_int;
     pub fn rt_scene_destroy(scene: *mut rt_scene);
     pub fn rt_scene_get_info(scene: *const rt_scene, out: *mut rt_scene_info) -> c_int;
     pub fn rt_scene_export_flat(scene: *const rt_scene, tri_vertices: *mut f64, tri_normals: *mut f64, tri_uvs: *mut f64, tri_obj: *mut i32, tri_idx: *mut i32) -> c_int;

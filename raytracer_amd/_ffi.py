@@ -28,6 +28,9 @@ RT_FLAG_NO_REGEN = 8
 RT_FLAG_MEGAKERNEL = 16
 RT_FLAG_PIPELINE = 32
 
+RT_TREE_HOST = 0
+RT_TREE_NONE = 1
+
 RT_BUILD_LBVH = 0
 RT_BUILD_PLOC = 1
 RT_BUILD_DEFAULT = RT_BUILD_PLOC
@@ -175,6 +178,8 @@ SIGNATURES = {
     "rt_render_params_default": (None, [_P]),
     "rt_scene_from_objects": (C.c_int, [_P, C.POINTER(_P)]),
     "rt_scene_create": (C.c_int, [C.POINTER(rt_scene_desc), C.POINTER(_P)]),
+    "rt_scene_from_objects_with": (C.c_int, [_P, C.c_uint32, C.POINTER(_P)]),
+    "rt_scene_create_with": (C.c_int, [C.POINTER(rt_scene_desc), C.c_uint32, C.POINTER(_P)]),
     "rt_scene_destroy": (None, [_P]),
     "rt_scene_get_info": (C.c_int, [_P, C.POINTER(rt_scene_info)]),
     "rt_scene_export_flat": (C.c_int, [_P, _P, _P, _P, _P, _P]),

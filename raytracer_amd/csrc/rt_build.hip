@@ -697,6 +697,7 @@ static int rt_scene_rebuild_on_device_body(rt_scene* s, int device, uint32_t met
   s->root_ref = root_ref;
   s->bvh_depth = depth;
   s->bvh_leaves = leaves;
+  s->has_tree = true;
   rt_fill_leaf_records(s);
   phase("records");
   return RT_OK;

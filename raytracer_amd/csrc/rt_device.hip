@@ -175,6 +175,10 @@ int rt_device_scene_upload_from(const rt_scene* s, rt_scene* target, int device)
     rt_set_error("rt_scene_upload: no HIP device is visible; this library has no CPU path");
     return RT_ERR_NO_DEVICE;
   }
+  if (!s->has_tree) {
+    rt_set_error("rt_scene_upload: the scene was created without a tree; build one with rt_scene_rebuild_on_device first");
+    return RT_ERR_INVALID;
+  }
   if (device < 0 || device >= n) {
     rt_set_error("rt_scene_upload: device %d out of range (0..%d)", device, n - 1);
     return RT_ERR_INVALID;

@@ -658,6 +658,7 @@ int build_scene_accel(rt_scene* s) {
   s->root_ref = RT_REF_SENTINEL;
   s->bvh_depth = 0;
   s->bvh_leaves = 0;
+  s->has_tree = true;
   if (n == 0) return RT_OK;
 
   // RT_BUILD_TIMING=1 prints the elapsed time after each phase of the build to stderr.
@@ -714,7 +715,13 @@ int build_scene_accel(rt_scene* s) {
 // ------------------------------------------------------------------------------------------
 // scenes
 // ------------------------------------------------------------------------------------------
-extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
+extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) { return rt_scene_create_with(d, RT_TREE_HOST, out); }
+
+extern "C" int rt_scene_create_with(const rt_scene_desc* d, uint32_t tree, rt_scene** out) {
+  if (tree != RT_TREE_HOST && tree != RT_TREE_NONE) {
+    rt_set_error("rt_scene_create: unknown tree option %u", tree);
+    return RT_ERR_INVALID;
+  }
   if (!d || !out) {
     rt_set_error("rt_scene_create: null argument");
     return RT_ERR_INVALID;
@@ -807,8 +814,10 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
       t.rgba.assign(d->textures[i].rgba, d->textures[i].rgba + (size_t)t.w * t.h * 4);
       s->textures.push_back(std::move(t));
     }
-    int rc = build_scene_accel(s.get());
-    if (rc != RT_OK) return rc;
+    if (tree == RT_TREE_HOST || d->n_triangles == 0) {  // a scene of spheres has no tree to wait for
+      int rc = build_scene_accel(s.get());
+      if (rc != RT_OK) return rc;
+    }
   } catch (const std::bad_alloc&) {
     rt_set_error("rt_scene_create: out of host memory");
     return RT_ERR_OOM;
@@ -821,6 +830,10 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
 // triangle order; the per-corner normals and texture coordinates that normal_at_hit and
 // get_tex_uv_coords would look up (src/main.rs:526-529, 481-483) are gathered here once.
 extern "C" int rt_scene_from_objects(const rt_objects* objs, rt_scene** out) {
+  return rt_scene_from_objects_with(objs, RT_TREE_HOST, out);
+}
+
+extern "C" int rt_scene_from_objects_with(const rt_objects* objs, uint32_t tree, rt_scene** out) {
   if (!objs || !out) {
     rt_set_error("rt_scene_from_objects: null argument");
     return RT_ERR_INVALID;
@@ -872,7 +885,7 @@ extern "C" int rt_scene_from_objects(const rt_objects* objs, rt_scene** out) {
     d.sphere_obj = sobj.data();
     d.n_textures = (uint32_t)tex.size();
     d.textures = tex.data();
-    return rt_scene_create(&d, out);
+    return rt_scene_create_with(&d, tree, out);
   } catch (const std::bad_alloc&) {
     rt_set_error("rt_scene_from_objects: out of host memory");
     return RT_ERR_OOM;
@@ -920,6 +933,10 @@ extern "C" int rt_scene_export_flat(const rt_scene* s, double* tv, double* tn, d
 extern "C" int rt_scene_export_bvh(const rt_scene* s, uint32_t* node_words, int32_t* leaf_order) {
   if (!s) {
     rt_set_error("rt_scene_export_bvh: null scene");
+    return RT_ERR_INVALID;
+  }
+  if (!s->has_tree) {
+    rt_set_error("rt_scene_export_bvh: the scene was created without a tree");
     return RT_ERR_INVALID;
   }
   if (node_words && !s->nodes.empty()) std::memcpy(node_words, s->nodes.data(), s->nodes.size() * sizeof(BvhNode));

@@ -6,10 +6,13 @@
 //
 //   rt_render SCENE_FILE [-o OUT.png] [--width W] [--height H] [--spp S] [--its N] [--seed K]
 //             [--max-depth D] [--device I | --devices I,J,... [--split samples|tiles]] [--progress]
+//             [--device-tree]
 //
 // Options override the scene file's `render` statement. --progress rewrites OUT.png after
 // every call, as the reference's window refreshes after every render event. --devices renders
 // every frame on a group of GPUs (one member per listed device, the first combines the frame).
+// --device-tree builds the tree on the GPU instead of the host (large scenes: a tenth of the build
+// time, frames somewhat slower).
 
 #include <hip/hip_runtime.h>
 
@@ -49,7 +52,7 @@ int main(int argc, char** argv) {
   std::string out_path = "render.png";
   long long o_w = -1, o_h = -1, o_spp = -1, o_its = -1, o_depth = -1, device = 0;
   unsigned long long o_seed = 0;
-  bool has_seed = false, progress = false;
+  bool has_seed = false, progress = false, device_tree = false;
   std::vector<int> devices;
   uint32_t split = RT_SPLIT_SAMPLES;
   for (int i = 1; i < argc; ++i) {
@@ -70,6 +73,7 @@ int main(int argc, char** argv) {
     else if (a == "--device") ok = value(&device);
     else if (a == "--seed" && i + 1 < argc) { o_seed = std::strtoull(argv[++i], nullptr, 10); has_seed = true; }
     else if (a == "--progress") progress = true;
+    else if (a == "--device-tree") device_tree = true;
     else if (a == "--devices" && i + 1 < argc) {
       for (const char* c = argv[++i]; ok && *c;) {
         char* end = nullptr;
@@ -88,7 +92,7 @@ int main(int argc, char** argv) {
     else ok = false;
     if (!ok) {
       std::fprintf(stderr, "usage: rt_render SCENE_FILE [-o OUT.png] [--width W] [--height H] [--spp S] [--its N] "
-                           "[--seed K] [--max-depth D] [--device I | --devices I,J,... [--split samples|tiles]] [--progress]\n");
+                           "[--seed K] [--max-depth D] [--device I | --devices I,J,... [--split samples|tiles]] [--progress] [--device-tree]\n");
       return 2;
     }
   }
@@ -114,8 +118,10 @@ int main(int argc, char** argv) {
 
   const auto t_build = std::chrono::steady_clock::now();
   rt_scene* scene = nullptr;
-  if (rt_scene_from_objects(objs, &scene) != RT_OK) return die("rt_scene_from_objects");
+  if (rt_scene_from_objects_with(objs, device_tree ? RT_TREE_NONE : RT_TREE_HOST, &scene) != RT_OK) return die("rt_scene_from_objects");
   rt_objects_destroy(objs);
+  if (device_tree && rt_scene_rebuild_on_device(scene, devices.empty() ? (int)device : devices[0]) != RT_OK)
+    return die("rt_scene_rebuild_on_device");
   rt_group* group = nullptr;
   if (!devices.empty()) {
     device = devices[0];

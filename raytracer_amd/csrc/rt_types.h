@@ -97,6 +97,7 @@ struct rt_scene {
   int32_t root_ref = RT_REF_SENTINEL;
   uint32_t bvh_depth = 0;
   uint32_t bvh_leaves = 0;
+  bool has_tree = false;  // false only between rt_scene_create_with(RT_TREE_NONE) and a device build
   DeviceScene* dev = nullptr;
 };
 

@@ -160,10 +160,12 @@ class Scene:
             lib.rt_scene_destroy(h)
 
     @staticmethod
-    def from_objects(objs):
-        """Scene::from_objects, src/main.rs:750-774."""
+    def from_objects(objs, tree="host"):
+        """Scene::from_objects, src/main.rs:750-774. tree="none" skips the host's tree build for
+        callers that build the tree on the GPU next (rebuild_on_device)."""
         out = C.c_void_p()
-        check(lib.rt_scene_from_objects(objs._h, C.byref(out)), "rt_scene_from_objects")
+        t = {"host": _ffi.RT_TREE_HOST, "none": _ffi.RT_TREE_NONE}[tree]
+        check(lib.rt_scene_from_objects_with(objs._h, t, C.byref(out)), "rt_scene_from_objects_with")
         return Scene(out.value)
 
     @staticmethod

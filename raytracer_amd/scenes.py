@@ -30,7 +30,7 @@ def _floor(objects, assets):
     objects.from_mesh(floor, Opaque(color=(0.7, 0.7, 0.7), metallic=0.1, how_metallic=0.0, diffuse=1.0))
 
 
-def sphere_scene(assets=ASSETS, spot_texture="spot_texture.png"):
+def sphere_scene(assets=ASSETS, spot_texture="spot_texture.png", tree="host"):
     spot_poly = load_obj(os.path.join(assets, "spot_triangulated.obj"))
     objects = Objects()
     spot_text = objects.add_texture(load_texture(os.path.join(assets, spot_texture)))
@@ -47,10 +47,10 @@ def sphere_scene(assets=ASSETS, spot_texture="spot_texture.png"):
     objects.sphere((0.3, -0.4, -1.4), 0.3, Dielectric(1.5))
     objects.sphere((-0.15, -0.6, -2.0), 0.1, Opaque((0.7, 0.0, 0.0), metallic=0.0, how_metallic=0.0, diffuse=1.0))
     objects.sphere((0.0, 0.3, -1.9), 0.1, Dielectric(1.5))
-    return Scene.from_objects(objects)
+    return Scene.from_objects(objects, tree)
 
 
-def lens_scene(assets=ASSETS, spot_texture="spot_texture.png"):
+def lens_scene(assets=ASSETS, spot_texture="spot_texture.png", tree="host"):
     spot_poly = load_obj(os.path.join(assets, "spot_triangulated.obj"))
     objects = Objects()
     spot_text = objects.add_texture(load_texture(os.path.join(assets, spot_texture)))
@@ -61,19 +61,19 @@ def lens_scene(assets=ASSETS, spot_texture="spot_texture.png"):
     mirror.translate((0.0, 0.9, -2.2))
     objects.from_mesh(mirror, Opaque(color=spot_text, metallic=0.0, how_metallic=0.0, diffuse=1.0))
     objects.sphere((0.0, -0.3, -1.9), 0.3, Dielectric(1.5))
-    return Scene.from_objects(objects)
+    return Scene.from_objects(objects, tree)
 
 
-def sphere_floor_scene(assets=ASSETS):
+def sphere_floor_scene(assets=ASSETS, tree="host"):
     objects = Objects()
     _floor(objects, assets)
     sphere = load_obj(os.path.join(assets, "sphere.obj"))  # src/main.rs:1353-1364
     sphere.translate((0.0, 2.0, -7.0))
     objects.from_mesh(sphere, Opaque((1.0, 0.3, 0.0), metallic=0.0, how_metallic=0.0, diffuse=0.9))
-    return Scene.from_objects(objects)
+    return Scene.from_objects(objects, tree)
 
 
-def ogre_scene(assets=ASSETS):
+def ogre_scene(assets=ASSETS, tree="host"):
     objects = Objects()
     ogre_text = objects.add_texture(load_texture(os.path.join(assets, "ogre", "diffuse.png")))
     ogre_normal = objects.add_texture(load_texture(os.path.join(assets, "ogre", "normalmap.png")))
@@ -82,10 +82,10 @@ def ogre_scene(assets=ASSETS):
     ogre.rotate_y(deg(20.0))
     ogre.translate((0.0, 0.0, -2.0))
     objects.from_mesh(ogre, Opaque(color=ogre_text, metallic=0.0, how_metallic=0.0, diffuse=0.9, normal=ogre_normal))
-    return Scene.from_objects(objects)
+    return Scene.from_objects(objects, tree)
 
 
-def spot_grid_scene(nx, nz, assets=ASSETS, spot_texture="spot_texture.png"):
+def spot_grid_scene(nx, nz, assets=ASSETS, spot_texture="spot_texture.png", tree="host"):
     objects = Objects()
     spot_text = objects.add_texture(load_texture(os.path.join(assets, spot_texture)))
     _floor(objects, assets)
@@ -96,20 +96,22 @@ def spot_grid_scene(nx, nz, assets=ASSETS, spot_texture="spot_texture.png"):
             m = turned.clone()
             m.translate(((ix - 0.5 * (nx - 1)) * 1.2, 0.0, -2.5 - iz * 1.2))
             objects.from_mesh(m, Opaque(color=spot_text, metallic=0.0, how_metallic=0.0, diffuse=1.0))
-    return Scene.from_objects(objects)
+    return Scene.from_objects(objects, tree)
 
 
 SCENES = {
     "spot": sphere_scene,
-    "spot_20k": lambda assets=ASSETS: sphere_scene(assets, "spot_texture_20k.png"),
+    "spot_20k": lambda assets=ASSETS, tree="host": sphere_scene(assets, "spot_texture_20k.png", tree),
     "lens": lens_scene,
     "sphere_floor": sphere_floor_scene,
     "ogre": ogre_scene,
 }
 
 
-def build(name, assets=ASSETS):
+def build(name, assets=ASSETS, tree="host"):
+    """tree="none": no tree is built on the host (the caller builds it on the GPU with
+    Scene.rebuild_on_device before the first upload)."""
     if name.startswith("spot_grid:"):
         nx, nz = name.split(":", 1)[1].split("x")
-        return spot_grid_scene(int(nx), int(nz), assets)
-    return SCENES[name](assets)
+        return spot_grid_scene(int(nx), int(nz), assets, tree=tree)
+    return SCENES[name](assets, tree=tree)

@@ -108,3 +108,29 @@ def test_million_triangle_scene_builds_in_milliseconds(method):
     host = scenes.build("spot_grid:14x14")
     for a, b in zip(s.primary_hits(p), host.primary_hits(p)):
         assert a.tobytes() == b.tobytes()
+
+
+def test_scene_without_a_host_tree(oracle):
+    """RT_TREE_NONE: creation skips the host build; nothing runs until the tree is built on the
+    GPU; afterwards every result equals the host-built scene's."""
+    host = scenes.build("ogre")
+    bare = scenes.build("ogre", tree="none")
+    i = bare.info()
+    assert i.n_triangles == host.info().n_triangles and i.bvh_nodes == 0
+    for call in (lambda: bare.upload(0), lambda: bare.hit([[0, 0, 0]], [[0, 0, -1]]), lambda: bare.export_bvh(),
+                 lambda: bare.render(np.zeros((8, 8, 3)), rt.render_params(width=8, height=8, spp=1)), lambda: rt.Group(bare, [0])):
+        with pytest.raises(rt.RtError, match="without a tree"):
+            call()
+    bare.rebuild_on_device(0)
+    assert 0 < bare.info().bvh_nodes < i.n_triangles
+    p = rt.render_params(width=96, height=54, spp=3, seed=2)
+    ca = np.zeros((54, 96, 3)); cb = np.zeros((54, 96, 3))
+    assert bare.render(ca, p) == host.render(cb, p)
+    assert ca.tobytes() == cb.tobytes()
+    # a scene of spheres has no tree to wait for
+    mat = rt.Opaque((0.5, 0.5, 0.5), 0, 1, 0)
+    objs = rt.Objects()
+    objs.sphere((0, 0, -3), 1.0, mat)
+    s = rt.Scene.from_objects(objs, tree="none")
+    assert s.hit([[0, 0, 0]], [[0, 0, -1]])["t"][0] == 2.0
+

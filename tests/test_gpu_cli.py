@@ -51,6 +51,13 @@ def test_cli_progress_and_errors(tmp_path):
     assert r.returncode == 1 and "cannot open" in r.stderr
     r = subprocess.run([CLI, scene_file, "--bogus"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 2 and "usage" in r.stderr
+    # the tree built on the GPU instead of the host: the same picture
+    a, b = tmp_path / "a.png", tmp_path / "b.png"
+    common = [scene_file, "--width", "64", "--height", "36", "--spp", "2", "--its", "2"]
+    assert subprocess.run([CLI] + common + ["-o", str(a)], capture_output=True, text=True, timeout=120).returncode == 0
+    r = subprocess.run([CLI] + common + ["-o", str(b), "--device-tree"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(rt.load_png(a), rt.load_png(b))
 
 
 @pytest.mark.parametrize("split", ["samples", "tiles"])

@@ -229,3 +229,20 @@ def test_tree_does_not_depend_on_builder_threads(monkeypatch):
     for nodes, order, depth, leaves in trees[1:]:
         assert np.array_equal(nodes, trees[0][0]) and np.array_equal(order, trees[0][1])
         assert (depth, leaves) == trees[0][2:]
+
+
+def test_scene_created_without_a_tree_waits_for_one():
+    bare = scenes.build("sphere_floor", tree="none")
+    full = scenes.build("sphere_floor")
+    assert bare.info().n_triangles == full.info().n_triangles == 321
+    assert bare.info().bvh_nodes == 0 and full.info().bvh_nodes > 0
+    for a, b in zip(bare.export_flat(), full.export_flat()):
+        assert np.array_equal(a, b, equal_nan=True)
+    with pytest.raises(_ffi.RtError, match="without a tree"):
+        bare.export_bvh()
+    import ctypes as C
+    out = C.c_void_p()
+    assert _ffi.lib.rt_scene_from_objects_with(None, 0, C.byref(out)) == _ffi.RT_ERR_INVALID
+    objs = rt.Objects()
+    assert _ffi.lib.rt_scene_from_objects_with(objs._h, 9, C.byref(out)) == _ffi.RT_ERR_INVALID
+

@@ -116,6 +116,11 @@ def main():
         if debug:
             print(f"[rank {rank} {time.perf_counter():.3f}] {msg}", file=sys.stderr, flush=True)
 
+    # N > 1: the reduction of a frame is queued on a stream of its own, behind a device-side wait for
+    # the frame (rt_scene_stream_wait): the frame's overlapped tail is then free to finish on the
+    # library's stream while the next frame's first stage already runs on the render stream.
+    reduce_stream = torch.cuda.Stream() if world > 1 else None
+
     def run_step(step, flags):
         note(f"step {step} flags {flags}")
         p = frame_params(step, flags)
@@ -124,14 +129,19 @@ def main():
         else:
             b = step & 1
             if in_flight[b] is not None:
-                in_flight[b].wait()
+                in_flight[b].wait()  # the render stream waits for the reduction that last used this buffer
             sums[b].zero_()
             scene.render_sum_f32_device(sums[b].data_ptr(), p, stream)
             note("rendered")
             if os.environ.get("RT_BENCH_SYNC_REDUCE"):  # A/B: reduce each frame before the next starts
+                scene.wait()
                 parallel.reduce_frame_sum(sums[b], dist)
             else:
-                in_flight[b] = parallel.reduce_frame_sum(sums[b], dist, async_op=True)
+                with torch.cuda.stream(reduce_stream):
+                    scene.stream_wait(reduce_stream.cuda_stream)
+                    in_flight[b] = parallel.reduce_frame_sum(sums[b], dist, async_op=True)
+                if backend != "nccl":  # the rehearsal backend reduces through the host and hands back no handle
+                    reduce_stream.synchronize()
             note("reduce queued")
 
     def drain():
@@ -140,6 +150,8 @@ def main():
                 in_flight[b].wait()
                 in_flight[b] = None
                 note(f"drained {b}")
+        if reduce_stream is not None:
+            reduce_stream.synchronize()
 
     def barrier():
         drain()
@@ -169,12 +181,13 @@ def main():
     if canvas is not None:
         canvas.zero_()
 
-    # Timed region. On one GPU the frames form a pipelined run (RT_FLAG_PIPELINE): each frame's
-    # thin tail of long paths and its sum into the canvas overlap the next frame's first stage,
+    # Timed region. The frames form a pipelined run (RT_FLAG_PIPELINE): each frame's thin tail of
+    # long paths and its sum into the canvas (or sum buffer) overlap the next frame's first stage,
     # as in the reference's display loop where frame follows frame; rt_scene_wait at the end is
-    # inside the timed region. With N > 1 every frame ends in a reduction, so frames are ordered
-    # on the stream and only the reduction overlaps the next frame.
-    pipelined = world == 1 and args.form == "wave" and not os.environ.get("RT_BENCH_NO_PIPELINE")
+    # inside the timed region. With N > 1 every frame's reduction follows its tail on the reduction
+    # stream, also behind the next frame.
+    pipelined = (args.form == "wave" and not os.environ.get("RT_BENCH_NO_PIPELINE")
+                 and not (world > 1 and os.environ.get("RT_BENCH_SYNC_REDUCE")))
     step_flags = _ffi.RT_FLAG_TIMING | (_ffi.RT_FLAG_PIPELINE if pipelined else 0)
     rays_total = 0
     timed = {}  # kernel kind -> [ms, launches, rays]

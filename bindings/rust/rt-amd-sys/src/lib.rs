@@ -212,6 +212,7 @@ extern "C" {
     pub fn rt_render_device(scene: *mut rt_scene, p: *const rt_render_params, device_canvas: *mut f64, stream: *mut c_void) -> c_int;
     pub fn rt_render_sum_f32_device(scene: *mut rt_scene, p: *const rt_render_params, device_sum: *mut f32, stream: *mut c_void) -> c_int;
     pub fn rt_scene_wait(scene: *mut rt_scene) -> c_int;
+    pub fn rt_scene_stream_wait(scene: *mut rt_scene, stream: *mut c_void) -> c_int;
     pub fn rt_group_create(scene: *const rt_scene, devices: *const c_int, n_devices: u32, out: *mut *mut rt_group) -> c_int;
     pub fn rt_group_destroy(group: *mut rt_group);
     pub fn rt_group_size(group: *const rt_group, n_members: *mut u32) -> c_int;

@@ -61,7 +61,8 @@ extern "C" {
                               /* the sum into the canvas) queued on a stream of the library's    */
                               /* own instead of the caller's, so that they overlap the next      */
                               /* call. The canvas is complete after rt_scene_wait (or any        */
-                              /* rt_scene_last_* call, or the next call without this flag).      */
+                              /* rt_scene_last_* call, or the next call without this flag); until */
+                              /* then it must neither be freed nor handed to anything else.      */
                               /* Consecutive pipelined calls on one stream form a run: their     */
                               /* counters, launch log and timing accumulate. The reference's     */
                               /* display loop (src/main.rs:1099-1112) is such a run.             */
@@ -327,6 +328,12 @@ int rt_render_sum_f32_device(rt_scene* scene, const rt_render_params* p, float* 
 
 /* Waits for everything the scene has queued, on the caller's stream and on the library's own. */
 int rt_scene_wait(rt_scene* scene);
+/* The same wait on the device instead of the host: work queued on `stream` after this call
+ * starts only when everything the scene has queued so far (on the stream of its render calls and
+ * on the library's own) has finished. Returns at once and does not end a run of pipelined calls:
+ * a reduction of the frame's sums can follow each pipelined call on a stream of its own while
+ * the next frame renders. */
+int rt_scene_stream_wait(rt_scene* scene, void* stream);
 
 /* Waits for the scene's queued work, then reports (for a run of pipelined calls: the run's
  * totals; the work of the overlapped tails is reported in total on the last tail of the log). */

@@ -196,6 +196,7 @@ SIGNATURES = {
     "rt_render_device": (C.c_int, [_P, C.POINTER(rt_render_params), _P, _P]),
     "rt_render_sum_f32_device": (C.c_int, [_P, C.POINTER(rt_render_params), _P, _P]),
     "rt_scene_wait": (C.c_int, [_P]),
+    "rt_scene_stream_wait": (C.c_int, [_P, _P]),
     "rt_group_create": (C.c_int, [_P, C.POINTER(C.c_int), C.c_uint32, C.POINTER(_P)]),
     "rt_group_destroy": (None, [_P]),
     "rt_group_size": (C.c_int, [_P, C.POINTER(C.c_uint32)]),

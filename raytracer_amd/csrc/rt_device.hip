@@ -68,6 +68,7 @@ struct DeviceScene {
   hipStream_t side = nullptr;
   hipEvent_t ev_gathered[2] = {nullptr, nullptr};  // main stream: chunk's tail input is complete
   hipEvent_t ev_resolved[2] = {nullptr, nullptr};  // side stream: chunk's samples have been summed
+  hipEvent_t ev_join = nullptr;                    // rt_scene_stream_wait: re-recorded at every call
   void* tail_in[2] = {nullptr, nullptr};           // compact tail input, one segment
   size_t tail_in_bytes[2] = {0, 0};
   double* tail_rad[2] = {nullptr, nullptr};
@@ -119,6 +120,7 @@ void rt_device_scene_free(DeviceScene* d) {
   if (d->tail_counters) (void)hipFree(d->tail_counters);
   if (d->host_snaps) (void)hipHostFree(d->host_snaps);
   if (d->side) (void)hipStreamDestroy(d->side);
+  if (d->ev_join) (void)hipEventDestroy(d->ev_join);
   for (int q = 0; q < 2; ++q) {
     if (d->ev_gathered[q]) (void)hipEventDestroy(d->ev_gathered[q]);
     if (d->ev_resolved[q]) (void)hipEventDestroy(d->ev_resolved[q]);
@@ -1471,6 +1473,29 @@ static int rt_scene_wait_body(rt_scene* s) {
   }
   if (!s->dev) return RT_OK;
   return finish_run(s->dev);
+}
+
+extern "C" int rt_scene_stream_wait(rt_scene* s, void* stream) {
+  return rt_guard("rt_scene_stream_wait", [&] {
+    if (!s) {
+      rt_set_error("rt_scene_stream_wait: null scene");
+      return RT_ERR_INVALID;
+    }
+    DeviceScene* d = s->dev;
+    if (!d) return RT_OK;
+    HIP_TRY(hipSetDevice(d->device));
+    if (!d->ev_join) HIP_TRY(hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming));
+    hipStream_t waiter = (hipStream_t)stream;
+    if (d->last_stream_valid && d->last_stream != waiter) {
+      HIP_TRY(hipEventRecord(d->ev_join, d->last_stream));
+      HIP_TRY(hipStreamWaitEvent(waiter, d->ev_join, 0));
+    }
+    if (d->side) {
+      HIP_TRY(hipEventRecord(d->ev_join, d->side));
+      HIP_TRY(hipStreamWaitEvent(waiter, d->ev_join, 0));
+    }
+    return RT_OK;
+  });
 }
 
 static int rt_scene_last_stats_body(rt_scene* s, rt_stats* out);

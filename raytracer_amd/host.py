@@ -302,6 +302,11 @@ class Scene:
         """Waits for everything the scene has queued (ends a run of pipelined calls)."""
         check(lib.rt_scene_wait(self._h), "rt_scene_wait")
 
+    def stream_wait(self, stream):
+        """Makes `stream` (a hipStream_t as an integer) wait on the device for everything the scene
+        has queued so far; returns at once."""
+        check(lib.rt_scene_stream_wait(self._h, C.c_void_p(stream or 0)), "rt_scene_stream_wait")
+
     def last_stats(self):
         s = _ffi.rt_stats()
         check(lib.rt_scene_last_stats(self._h, C.byref(s)), "rt_scene_last_stats")

@@ -83,3 +83,28 @@ def test_pipelined_f32_sums_and_host_entry_point(spot, one_by_one):
     c = np.zeros((H, W, 3))  # the blocking entry point accepts the flag and still returns a finished canvas
     assert [spot.render(c, frame(i, _ffi.RT_FLAG_PIPELINE)) for i in range(ITS)] == rays
     assert c.tobytes() == want.tobytes()
+
+
+def test_stream_wait_orders_another_stream_behind_a_pipelined_frame(spot):
+    """rt_scene_stream_wait: what a second stream reads after the wait is the finished frame, although
+    the host never waited and the run goes on (the multi-GPU loop queues each frame's reduction so)."""
+    big = dict(width=640, height=480, spp=4, seed=3)
+    ref = torch.zeros((480, 640, 3), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    spot.render_sum_f32_device(ref.data_ptr(), rt.render_params(**big), stream)
+    spot.wait()
+    other = torch.cuda.Stream()
+    copies = []
+    bufs = [torch.zeros((480, 640, 3), dtype=torch.float32, device="cuda") for _ in range(4)]  # alive until the run ends
+    for buf in bufs:
+        spot.render_sum_f32_device(buf.data_ptr(), rt.render_params(flags=_ffi.RT_FLAG_PIPELINE, **big), stream)
+        with torch.cuda.stream(other):
+            spot.stream_wait(other.cuda_stream)
+            copies.append(buf.clone())  # runs on `other`, behind the frame's tail and sum
+    other.synchronize()
+    for c in copies:
+        assert torch.equal(c, ref)
+    spot.wait()
+    assert spot.last_stats().rays > 0
+    fresh = scenes.build("sphere_floor")
+    fresh.stream_wait(0)  # nothing uploaded, nothing queued: returns at once

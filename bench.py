@@ -45,7 +45,7 @@ FP32_PEAK_TFLOPS = 157.3
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)  # 0.6 s of frames: the run's first and last frame have nothing to overlap with
+    ap.add_argument("--steps", type=int, default=40)  # 0.6 s of frames: the first frames after a pause run a few per cent slower
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="sphere_floor_1080p_64spp", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")

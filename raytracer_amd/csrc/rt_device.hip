@@ -449,6 +449,31 @@ __global__ __launch_bounds__(RT_BLOCK) void k_primary(SceneK sc, CameraK cam, in
   flush_counts(wc, counters, false, 0);
 }
 
+// Division of any 32-bit unsigned number by a divisor known on the host, as a multiplication
+// (Granlund and Montgomery, "Division by invariant integers using multiplication", 1994): on
+// wave-uniform operands it stays on the scalar unit, which has no divide.
+struct FastDiv {
+  uint32_t m, sh1, sh2;
+};
+static FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f{1u, 0u, 0u};
+  if (d <= 1u) return f;  // n / 1 = n (a zero divisor never reaches a kernel)
+  uint32_t l = 0;
+  while (l < 32u && (1ull << l) < d) ++l;  // ceil(log2 d)
+  f.m = (uint32_t)((((1ull << l) - d) << 32) / d + 1ull);
+  f.sh1 = 1u;
+  f.sh2 = l - 1u;
+  return f;
+}
+__host__ __device__ inline uint32_t fastdiv(uint32_t n, const FastDiv& f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint32_t q = __umulhi(n, f.m);
+#else
+  const uint32_t q = (uint32_t)(((unsigned long long)n * f.m) >> 32);
+#endif
+  return (q + ((n - q) >> f.sh1)) >> f.sh2;
+}
+
 // Which pixels a call renders and how path indices map onto them.
 struct TileMap {
   uint32_t width, height;
@@ -457,19 +482,22 @@ struct TileMap {
   uint32_t bigs_x;       // big tiles per image row
   uint32_t rank, ranks;  // this call renders big tiles rank, rank + ranks, ...
   uint32_t n_tiles;      // 8x8 tiles this call renders
+  FastDiv d_tiles_x, d_big, d_per_big, d_bigs_x;
 };
 
 __host__ __device__ inline bool tile_pixel(const TileMap& tm, uint32_t tile, uint32_t lane_pix, uint32_t* x, uint32_t* y) {
   uint32_t tx, ty;
   if (tm.big == 0) {
-    tx = tile % tm.tiles_x;
-    ty = tile / tm.tiles_x;
+    ty = fastdiv(tile, tm.d_tiles_x);
+    tx = tile - ty * tm.tiles_x;
   } else {
     const uint32_t per_big = tm.big * tm.big;
-    const uint32_t b = tm.rank + (tile / per_big) * tm.ranks;
-    const uint32_t j = tile % per_big;
-    tx = (b % tm.bigs_x) * tm.big + j % tm.big;
-    ty = (b / tm.bigs_x) * tm.big + j / tm.big;
+    const uint32_t bi = fastdiv(tile, tm.d_per_big);
+    const uint32_t b = tm.rank + bi * tm.ranks;
+    const uint32_t j = tile - bi * per_big;
+    const uint32_t by = fastdiv(b, tm.d_bigs_x), jy = fastdiv(j, tm.d_big);
+    tx = (b - by * tm.bigs_x) * tm.big + (j - jy * tm.big);
+    ty = by * tm.big + jy;
   }
   *x = tx * 8u + (lane_pix & 7u);
   *y = ty * 8u + (lane_pix >> 3);
@@ -482,6 +510,7 @@ struct PathParams {
   uint64_t seed;
   uint32_t n_paths;       // n_tiles * spp * 64, < 2^32 per launch
   uint32_t spp;           // samples in this launch
+  FastDiv d_spp;
   uint32_t first_sample;  // stream index of this launch's sample 0
   int32_t max_depth;
   uint32_t fuse_bounces;  // bounces the first wavefront stage follows before it queues its hits
@@ -490,9 +519,10 @@ struct PathParams {
 
 // Path index -> pixel and sample; starts the path (camera ray, src/main.rs:995-1013).
 // Returns false for the padding lanes of tiles that overhang the image.
-__device__ __forceinline__ bool start_path(const PathParams& pp, uint32_t path, uint64_t& key, d3& o, d3& dir) {
-  const uint32_t g = path >> 6;  // tile * spp + sample
-  const uint32_t tile = g / pp.spp;
+// `g` = path >> 6 = tile * spp + sample: the same for the 64 paths of a wave, so callers whose
+// blocks are one wave pass their block index and the arithmetic stays on the scalar unit.
+__device__ __forceinline__ bool start_path(const PathParams& pp, uint32_t g, uint32_t path, uint64_t& key, d3& o, d3& dir) {
+  const uint32_t tile = fastdiv(g, pp.d_spp);
   const uint32_t s = g - tile * pp.spp;
   uint32_t x, y;
   if (!tile_pixel(pp.tm, tile, path & 63u, &x, &y)) return false;
@@ -546,7 +576,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_paths(SceneK sc, PathParams pp, do
     exhausted = true;
     if (p64 < pp.n_paths) {
       path = (uint32_t)p64;
-      alive = start_path(pp, path, key, o, dir);
+      alive = start_path(pp, path >> 6, path, key, o, dir);
       if (!alive) store_sample(samples, pp.n_paths, path, mk(0.0, 0.0, 0.0));
     }
   }
@@ -574,7 +604,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_paths(SceneK sc, PathParams pp, do
           thr = mk(1.0, 1.0, 1.0);
           rad = mk(0.0, 0.0, 0.0);
           depth = 0;
-          alive = start_path(pp, path, key, o, dir);
+          alive = start_path(pp, path >> 6, path, key, o, dir);
           if (!alive) store_sample(samples, pp.n_paths, path, mk(0.0, 0.0, 0.0));
         }
         local_next += min(avail, (uint32_t)__popcll(need));
@@ -712,7 +742,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
   if (alive) {
     if (STAGE == 0) {
       path = blockIdx.x * RT_BLOCK + threadIdx.x;
-      alive = start_path(pp, path, key, o, dir);
+      alive = start_path(pp, RT_BLOCK == 64 ? blockIdx.x : path >> 6, path, key, o, dir);
       if (!alive) store_sample(samples, pp.n_paths, path, mk(0.0, 0.0, 0.0));
     } else {
       const QueueRec* r = in.recs + entry;
@@ -981,6 +1011,10 @@ static TileMap make_tilemap(const rt_render_params* p) {
     const uint32_t mine = n_big > tm.rank ? (n_big - tm.rank + tm.ranks - 1) / tm.ranks : 0;
     tm.n_tiles = mine * tm.big * tm.big;
   }
+  tm.d_tiles_x = make_fastdiv(tm.tiles_x);
+  tm.d_big = make_fastdiv(tm.big);
+  tm.d_per_big = make_fastdiv(tm.big * tm.big);
+  tm.d_bigs_x = make_fastdiv(tm.bigs_x);
   return tm;
 }
 
@@ -1184,6 +1218,7 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
     pp.tm = tm;
     pp.seed = p->seed;
     pp.spp = std::min(chunk, p->spp - c * chunk);
+    pp.d_spp = make_fastdiv(pp.spp);
     pp.first_sample = p->first_sample + c * chunk;
     pp.n_paths = (uint32_t)(n_pix * pp.spp);
     pp.max_depth = p->max_depth;

@@ -545,38 +545,50 @@ struct Builder {
     if (n > 1 && !must_balance) {
       double best_cost = std::numeric_limits<double>::infinity();
       int best_axis = -1, best_bin = -1;
+      // one pass over the triangles fills the bins of all three axes (a triangle's box and centre
+      // are read once, not three times)
+      Box bb[3][N_BINS];
+      size_t cnt[3][N_BINS];
+      double c0[3], scale[3];
+      bool usable[3];
       for (int axis = 0; axis < 3; ++axis) {
-        const double c0 = cb.lo[axis], ext = cb.hi[axis] - cb.lo[axis];
-        if (!(ext > 0.0) || !std::isfinite(ext)) continue;
-        Box bb[N_BINS];
-        size_t cnt[N_BINS];
+        const double ext = cb.hi[axis] - cb.lo[axis];
+        usable[axis] = ext > 0.0 && std::isfinite(ext);
+        c0[axis] = cb.lo[axis];
+        scale[axis] = usable[axis] ? (double)N_BINS / ext : 0.0;
         for (int b = 0; b < N_BINS; ++b) {
-          bb[b] = box_empty();
-          cnt[b] = 0;
+          bb[axis][b] = box_empty();
+          cnt[axis][b] = 0;
         }
-        const double scale = (double)N_BINS / ext;
-        for (size_t i = lo; i < hi; ++i) {
-          const int32_t t = idx[i];
-          int b = (int)((cen[(size_t)t * 3 + axis] - c0) * scale);
+      }
+      for (size_t i = lo; i < hi; ++i) {
+        const int32_t t = idx[i];
+        const Box& box = tb[t];
+        for (int axis = 0; axis < 3; ++axis) {
+          if (!usable[axis]) continue;
+          int b = (int)((cen[(size_t)t * 3 + axis] - c0[axis]) * scale[axis]);
           b = std::min(std::max(b, 0), N_BINS - 1);
-          cnt[b]++;
-          box_grow(bb[b], tb[t]);
+          cnt[axis][b]++;
+          box_grow(bb[axis][b], box);
         }
+      }
+      for (int axis = 0; axis < 3; ++axis) {
+        if (!usable[axis]) continue;
         double right_area[N_BINS];
         size_t right_cnt[N_BINS];
         Box acc = box_empty();
         size_t c = 0;
         for (int b = N_BINS - 1; b > 0; --b) {
-          box_grow(acc, bb[b]);
-          c += cnt[b];
+          box_grow(acc, bb[axis][b]);
+          c += cnt[axis][b];
           right_area[b] = box_half_area(acc);
           right_cnt[b] = c;
         }
         acc = box_empty();
         c = 0;
         for (int b = 0; b < N_BINS - 1; ++b) {
-          box_grow(acc, bb[b]);
-          c += cnt[b];
+          box_grow(acc, bb[axis][b]);
+          c += cnt[axis][b];
           if (c == 0 || right_cnt[b + 1] == 0) continue;
           double cost = box_half_area(acc) * (double)c + right_area[b + 1] * (double)right_cnt[b + 1];
           if (cost < best_cost) {
@@ -590,13 +602,13 @@ struct Builder {
         const double area = box_half_area(bounds);
         const double split_cost = COST_NODE + (area > 0.0 ? best_cost / area : (double)n) * COST_TRI;
         if (n > RT_LEAF_MAX || split_cost < (double)n * COST_TRI) {
-          const double c0 = cb.lo[best_axis], scale = (double)N_BINS / (cb.hi[best_axis] - cb.lo[best_axis]);
+          const double part_c0 = c0[best_axis], part_scale = scale[best_axis];
           // stable partition through the builder's scratch array (ranges of concurrent subtree
           // builds are disjoint, so they share it without locking)
           size_t nl = lo, nr = lo;
           for (size_t i = lo; i < hi; ++i) {
             const int32_t t = idx[i];
-            int b = (int)((cen[(size_t)t * 3 + best_axis] - c0) * scale);
+            int b = (int)((cen[(size_t)t * 3 + best_axis] - part_c0) * part_scale);
             b = std::min(std::max(b, 0), N_BINS - 1);
             if (b <= best_bin)
               idx[nl++] = t;

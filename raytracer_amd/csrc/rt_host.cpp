@@ -729,7 +729,19 @@ int build_scene_accel(rt_scene* s) {
 // ------------------------------------------------------------------------------------------
 extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) { return rt_scene_create_with(d, RT_TREE_HOST, out); }
 
+// The triangle arrays of a description the library assembled itself (rt_scene_from_objects): the
+// scene takes them over instead of copying them.
+struct OwnedTriangles {
+  std::vector<double> tv, tn, tuv;
+  std::vector<int32_t> tobj, tidx;
+};
+static int scene_create(const rt_scene_desc* d, uint32_t tree, rt_scene** out, OwnedTriangles* owned);
+
 extern "C" int rt_scene_create_with(const rt_scene_desc* d, uint32_t tree, rt_scene** out) {
+  return scene_create(d, tree, out, nullptr);
+}
+
+static int scene_create(const rt_scene_desc* d, uint32_t tree, rt_scene** out, OwnedTriangles* owned) {
   if (tree != RT_TREE_HOST && tree != RT_TREE_NONE) {
     rt_set_error("rt_scene_create: unknown tree option %u", tree);
     return RT_ERR_INVALID;
@@ -802,7 +814,13 @@ extern "C" int rt_scene_create_with(const rt_scene_desc* d, uint32_t tree, rt_sc
     s->object_kind.assign(d->object_kind, d->object_kind + d->n_objects);
     s->materials.assign(d->materials, d->materials + d->n_objects);
     const size_t n = (size_t)d->n_triangles;
-    if (n) {
+    if (n && owned) {
+      s->tri_vertices.swap(owned->tv);
+      s->tri_normals.swap(owned->tn);
+      s->tri_uvs.swap(owned->tuv);
+      s->tri_obj.swap(owned->tobj);
+      s->tri_idx.swap(owned->tidx);
+    } else if (n) {
       s->tri_vertices.assign(d->tri_vertices, d->tri_vertices + n * 9);
       s->tri_normals.assign(d->tri_normals, d->tri_normals + n * 9);
       s->tri_uvs.assign(d->tri_uvs, d->tri_uvs + n * 6);
@@ -853,32 +871,53 @@ extern "C" int rt_scene_from_objects_with(const rt_objects* objs, uint32_t tree,
   try {
     std::vector<int32_t> kinds;
     std::vector<rt_material> mats;
-    std::vector<double> tv, tn, tuv, sph;
-    std::vector<int32_t> tobj, tidx, sobj;
-    for (size_t oi = 0; oi < objs->items.size(); ++oi) {
+    std::vector<double> sph;
+    std::vector<int32_t> sobj;
+    const size_t n_obj = objs->items.size();
+    std::vector<size_t> first(n_obj + 1, 0);  // flat index of every object's first triangle
+    for (size_t oi = 0; oi < n_obj; ++oi) {
       const HostObject& o = objs->items[oi];
       kinds.push_back(o.kind);
       mats.push_back(o.mat);
+      first[oi + 1] = first[oi];
       if (o.kind == RT_OBJ_SPHERE) {
         sph.insert(sph.end(), {o.centre[0], o.centre[1], o.centre[2], o.radius});
         sobj.push_back((int32_t)oi);
-        continue;
-      }
-      const rt_mesh& m = o.mesh;
-      const size_t nt = m.tri_vertex.size() / 3;
-      for (size_t t = 0; t < nt; ++t) {
-        for (int k = 0; k < 3; ++k) {
-          const D3& v = m.vertices[m.tri_vertex[t * 3 + k]];
-          const D3& nn = m.vertex_normals[m.tri_vertex[t * 3 + k]];
-          tv.insert(tv.end(), {v.x, v.y, v.z});
-          tn.insert(tn.end(), {nn.x, nn.y, nn.z});
-          const uint64_t ui = m.tri_uv[t * 3 + k];
-          tuv.insert(tuv.end(), {m.uvs[ui * 2], m.uvs[ui * 2 + 1]});
-        }
-        tobj.push_back((int32_t)oi);
-        tidx.push_back((int32_t)t);
+      } else {
+        first[oi + 1] += o.mesh.tri_vertex.size() / 3;
       }
     }
+    const size_t total = first[n_obj];
+    OwnedTriangles own;
+    own.tv.resize(total * 9);
+    own.tn.resize(total * 9);
+    own.tuv.resize(total * 6);
+    own.tobj.resize(total);
+    own.tidx.resize(total);
+    parallel_ranges(n_obj, 16, [&](size_t, size_t begin, size_t end) {
+      for (size_t oi = begin; oi < end; ++oi) {
+        const HostObject& o = objs->items[oi];
+        if (o.kind == RT_OBJ_SPHERE) continue;
+        const rt_mesh& m = o.mesh;
+        const size_t nt = m.tri_vertex.size() / 3;
+        for (size_t t = 0; t < nt; ++t) {
+          const size_t f = first[oi] + t;
+          for (int k = 0; k < 3; ++k) {
+            const D3& v = m.vertices[m.tri_vertex[t * 3 + k]];
+            const D3& nn = m.vertex_normals[m.tri_vertex[t * 3 + k]];
+            double* pv = &own.tv[f * 9 + k * 3];
+            double* pn = &own.tn[f * 9 + k * 3];
+            pv[0] = v.x, pv[1] = v.y, pv[2] = v.z;
+            pn[0] = nn.x, pn[1] = nn.y, pn[2] = nn.z;
+            const uint64_t ui = m.tri_uv[t * 3 + k];
+            own.tuv[f * 6 + k * 2] = m.uvs[ui * 2];
+            own.tuv[f * 6 + k * 2 + 1] = m.uvs[ui * 2 + 1];
+          }
+          own.tobj[f] = (int32_t)oi;
+          own.tidx[f] = (int32_t)t;
+        }
+      }
+    });
     std::vector<rt_texture> tex;
     for (const HostTexture& t : objs->textures) tex.push_back(rt_texture{t.rgba.data(), t.w, t.h});
     rt_scene_desc d;
@@ -886,18 +925,18 @@ extern "C" int rt_scene_from_objects_with(const rt_objects* objs, uint32_t tree,
     d.n_objects = (uint32_t)kinds.size();
     d.object_kind = kinds.data();
     d.materials = mats.data();
-    d.n_triangles = tobj.size();
-    d.tri_vertices = tv.data();
-    d.tri_normals = tn.data();
-    d.tri_uvs = tuv.data();
-    d.tri_obj = tobj.data();
-    d.tri_idx = tidx.data();
+    d.n_triangles = total;
+    d.tri_vertices = own.tv.data();
+    d.tri_normals = own.tn.data();
+    d.tri_uvs = own.tuv.data();
+    d.tri_obj = own.tobj.data();
+    d.tri_idx = own.tidx.data();
     d.n_spheres = (uint32_t)sobj.size();
     d.spheres = sph.data();
     d.sphere_obj = sobj.data();
     d.n_textures = (uint32_t)tex.size();
     d.textures = tex.data();
-    return rt_scene_create_with(&d, tree, out);
+    return scene_create(&d, tree, out, &own);
   } catch (const std::bad_alloc&) {
     rt_set_error("rt_scene_from_objects: out of host memory");
     return RT_ERR_OOM;

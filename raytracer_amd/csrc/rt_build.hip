@@ -539,21 +539,7 @@ static int rt_scene_rebuild_on_device_body(rt_scene* s, int device, uint32_t met
 
   // centre bounds of the triangle boxes, for the quantisation of the Morton codes
   double clo[3], chi[3];
-  for (int c = 0; c < 3; ++c) {
-    clo[c] = std::numeric_limits<double>::infinity();
-    chi[c] = -std::numeric_limits<double>::infinity();
-  }
-  for (size_t t = 0; t < n; ++t) {
-    const double* v = &s->tri_vertices[t * 9];
-    for (int c = 0; c < 3; ++c) {
-      const double lo = std::min(v[c], std::min(v[3 + c], v[6 + c])), hi = std::max(v[c], std::max(v[3 + c], v[6 + c]));
-      const double m = 0.5 * lo + 0.5 * hi;
-      if (std::isfinite(m)) {
-        clo[c] = std::min(clo[c], m);
-        chi[c] = std::max(chi[c], m);
-      }
-    }
-  }
+  rt_scene_centre_bounds(s, clo, chi);
   // One scale for the three axes: the cells of the Morton grid are cubes, so neighbours along the
   // curve are neighbours in space whatever the proportions of the scene (a field of meshes 40 times
   // wider than tall, quantised per axis, would be sliced into sheets first).
@@ -618,6 +604,7 @@ static int rt_scene_rebuild_on_device_body(rt_scene* s, int device, uint32_t met
     uint32_t rounds = 0;
     if ((rc = ploc_rounds(mem, (uint32_t)n, d_vals_sorted, d_tri_boxes, d_nbox, d_ncount, d_nparent, d_child, d_nleaf, d_nnodes, &rounds)) != RT_OK)
       return rc;
+    phase("cluster");
     const uint32_t grid_i = (uint32_t)((ni + BUILD_BLOCK - 1) / BUILD_BLOCK);
     hipLaunchKernelGGL(k_ploc_mark, dim3(grid_i), dim3(BUILD_BLOCK), 0, nullptr, (uint32_t)ni, (uint32_t)n, d_ncount, d_nleaf, d_nparent, d_kept);
     HIP_TRY_B(hipGetLastError());
@@ -640,6 +627,7 @@ static int rt_scene_rebuild_on_device_body(rt_scene* s, int device, uint32_t met
                    stats[1], RT_BVH_MAX_DEPTH);
       return BUILD_TOO_DEEP;
     }
+    phase("emit");
     nodes.resize(n_kept);
     HIP_TRY_B(hipMemcpy(nodes.data(), d_nodes, (size_t)n_kept * sizeof(BvhNode), hipMemcpyDeviceToHost));
     root_ref = 0;
@@ -685,7 +673,7 @@ static int rt_scene_rebuild_on_device_body(rt_scene* s, int device, uint32_t met
     leaves = stats[0];
   }
   HIP_TRY_B(hipMemcpy(leaf_order.data(), order_on_device ? d_leaf_order : d_vals_sorted, n * sizeof(int32_t), hipMemcpyDeviceToHost));
-  phase("tree");
+  phase("copy out");
 
   // the scene takes the new tree; its device copy, if any, is stale
   if (s->dev) {

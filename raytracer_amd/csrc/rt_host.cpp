@@ -425,6 +425,45 @@ double rt_scene_box_pad(const rt_scene* s) {
   return extent * 9.5367431640625e-07;
 }
 
+// Bounds of the centres of the triangles' boxes (finite ones only), for the Morton grid of the
+// device tree builders. Minima and maxima: the same whatever the pieces.
+void rt_scene_centre_bounds(const rt_scene* s, double clo[3], double chi[3]) {
+  const size_t n = s->tri_obj.size();
+  const double inf = std::numeric_limits<double>::infinity();
+  std::vector<double> part(64 * 6);
+  for (size_t k = 0; k < 64; ++k)
+    for (int c = 0; c < 3; ++c) {
+      part[k * 6 + c] = inf;
+      part[k * 6 + 3 + c] = -inf;
+    }
+  parallel_ranges(n, 1u << 18, [&](size_t piece, size_t begin, size_t end) {
+    double lo3[3] = {inf, inf, inf}, hi3[3] = {-inf, -inf, -inf};
+    for (size_t t = begin; t < end; ++t) {
+      const double* v = &s->tri_vertices[t * 9];
+      for (int c = 0; c < 3; ++c) {
+        const double lo = std::min(v[c], std::min(v[3 + c], v[6 + c])), hi = std::max(v[c], std::max(v[3 + c], v[6 + c]));
+        const double m = 0.5 * lo + 0.5 * hi;
+        if (std::isfinite(m)) {
+          lo3[c] = std::min(lo3[c], m);
+          hi3[c] = std::max(hi3[c], m);
+        }
+      }
+    }
+    for (int c = 0; c < 3; ++c) {
+      part[piece * 6 + c] = lo3[c];
+      part[piece * 6 + 3 + c] = hi3[c];
+    }
+  });
+  for (int c = 0; c < 3; ++c) {
+    clo[c] = inf;
+    chi[c] = -inf;
+    for (size_t k = 0; k < 64; ++k) {
+      clo[c] = std::min(clo[c], part[k * 6 + c]);
+      chi[c] = std::max(chi[c], part[k * 6 + 3 + c]);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // acceleration structure
 // ------------------------------------------------------------------------------------------

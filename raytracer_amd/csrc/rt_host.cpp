@@ -425,6 +425,14 @@ double rt_scene_box_pad(const rt_scene* s) {
   return extent * 9.5367431640625e-07;
 }
 
+// dst[i] += src[i] on the builder's threads (the host-buffer render entry point adds a frame to the
+// caller's canvas with it).
+void rt_add_into(double* dst, const double* src, size_t n) {
+  parallel_ranges(n, 1u << 18, [=](size_t, size_t begin, size_t end) {
+    for (size_t i = begin; i < end; ++i) dst[i] += src[i];
+  });
+}
+
 // Bounds of the centres of the triangles' boxes (finite ones only), for the Morton grid of the
 // device tree builders. Minima and maxima: the same whatever the pieces.
 void rt_scene_centre_bounds(const rt_scene* s, double clo[3], double chi[3]) {

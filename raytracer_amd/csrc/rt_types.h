@@ -126,6 +126,7 @@ static inline int rt_guard(const char* who, F&& body) noexcept {
 void rt_fill_leaf_records(rt_scene* s);
 double rt_scene_box_pad(const rt_scene* s);
 unsigned rt_build_threads();
+void rt_add_into(double* dst, const double* src, size_t n);
 void rt_scene_centre_bounds(const rt_scene* s, double clo[3], double chi[3]);
 // rt_device.hip
 void rt_device_scene_free(DeviceScene* d);

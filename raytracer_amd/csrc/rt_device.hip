@@ -68,7 +68,7 @@ struct DeviceScene {
   hipStream_t side = nullptr;
   hipEvent_t ev_gathered[2] = {nullptr, nullptr};  // main stream: chunk's tail input is complete
   hipEvent_t ev_resolved[2] = {nullptr, nullptr};  // side stream: chunk's samples have been summed
-  hipEvent_t ev_join = nullptr;                    // rt_scene_stream_wait: re-recorded at every call
+  hipEvent_t ev_join[2] = {nullptr, nullptr};      // rt_scene_stream_wait: caller's stream, side stream; re-recorded per call
   void* tail_in[2] = {nullptr, nullptr};           // compact tail input, one segment
   size_t tail_in_bytes[2] = {0, 0};
   double* tail_rad[2] = {nullptr, nullptr};
@@ -122,7 +122,8 @@ void rt_device_scene_free(DeviceScene* d) {
   if (d->tail_counters) (void)hipFree(d->tail_counters);
   if (d->host_snaps) (void)hipHostFree(d->host_snaps);
   if (d->side) (void)hipStreamDestroy(d->side);
-  if (d->ev_join) (void)hipEventDestroy(d->ev_join);
+  for (int q = 0; q < 2; ++q)
+    if (d->ev_join[q]) (void)hipEventDestroy(d->ev_join[q]);
   for (int q = 0; q < 2; ++q) {
     if (d->ev_gathered[q]) (void)hipEventDestroy(d->ev_gathered[q]);
     if (d->ev_resolved[q]) (void)hipEventDestroy(d->ev_resolved[q]);
@@ -1534,15 +1535,16 @@ extern "C" int rt_scene_stream_wait(rt_scene* s, void* stream) {
     DeviceScene* d = s->dev;
     if (!d) return RT_OK;
     HIP_TRY(hipSetDevice(d->device));
-    if (!d->ev_join) HIP_TRY(hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming));
+    for (int q = 0; q < 2; ++q)
+      if (!d->ev_join[q]) HIP_TRY(hipEventCreateWithFlags(&d->ev_join[q], hipEventDisableTiming));
     hipStream_t waiter = (hipStream_t)stream;
     if (d->last_stream_valid && d->last_stream != waiter) {
-      HIP_TRY(hipEventRecord(d->ev_join, d->last_stream));
-      HIP_TRY(hipStreamWaitEvent(waiter, d->ev_join, 0));
+      HIP_TRY(hipEventRecord(d->ev_join[0], d->last_stream));
+      HIP_TRY(hipStreamWaitEvent(waiter, d->ev_join[0], 0));
     }
     if (d->side) {
-      HIP_TRY(hipEventRecord(d->ev_join, d->side));
-      HIP_TRY(hipStreamWaitEvent(waiter, d->ev_join, 0));
+      HIP_TRY(hipEventRecord(d->ev_join[1], d->side));
+      HIP_TRY(hipStreamWaitEvent(waiter, d->ev_join[1], 0));
     }
     return RT_OK;
   });

@@ -319,7 +319,8 @@ int rt_primary_hits(rt_scene* scene, const rt_render_params* p, int32_t* obj, in
 int rt_render_accumulate(rt_scene* scene, const rt_render_params* p, double* canvas, uint64_t* rays_out);
 
 /* Same with the canvas in device memory and the work queued on `stream` (a hipStream_t, NULL
- * for the default stream); returns without waiting. */
+ * for the default stream); returns without waiting. The scene remembers the stream (later calls
+ * and rt_scene_wait synchronise with it), so it must outlive the scene's next call. */
 int rt_render_device(rt_scene* scene, const rt_render_params* p, double* device_canvas, void* stream);
 
 /* Sample-split rendering for several GPUs: device_sum[v][u][c] += sum (not mean) of this

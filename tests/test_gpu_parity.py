@@ -417,3 +417,24 @@ def test_full_size_tile_union(gpu_scenes):
         assert np.count_nonzero(union.any(axis=2)) - before > w * h // 10  # every rank owns about an eighth
     assert parts == rays
     assert sha(union) == sha(whole)
+
+
+@pytest.mark.parametrize("name", ["spot", "sphere_floor", "ogre"])
+def test_work_counters_equal_the_cpu_restatement(gpu_scenes, oracle, name):
+    """The node visits and triangle tests the kernels count (what the roofline's algorithmic bytes
+    are computed from) against the oracle's restatement of the same traversal over the same tree,
+    ray for ray the same walk: equal up to the handful of box tests that the hardware reciprocal
+    decides differently (the restatement perturbs the reciprocal by an ulp to stand in for it)."""
+    s = gpu_scenes(name)
+    o = oracle.OracleScene.build(name)
+    co, cd = oracle.camera_rays(320, 240)
+    rng = np.random.default_rng(1)
+    org = np.concatenate([co, rng.normal(size=(50000, 3)) * 2 + np.array([0, 0, -3.0])])
+    d = np.concatenate([cd, rng.normal(size=(50000, 3))])
+    s.hit(org, d)
+    st = s.last_stats()
+    nodes, order = s.export_bvh()
+    _, (node_visits, tri_tests) = o.bvh_hit(nodes, order, 0, org, d)
+    assert st.rays == len(org)
+    assert abs(st.node_visits - node_visits) <= 1e-4 * node_visits, (st.node_visits, node_visits)
+    assert abs(st.tri_tests - tri_tests) <= 1e-4 * tri_tests, (st.tri_tests, tri_tests)

@@ -438,3 +438,23 @@ def test_work_counters_equal_the_cpu_restatement(gpu_scenes, oracle, name):
     assert st.rays == len(org)
     assert abs(st.node_visits - node_visits) <= 1e-4 * node_visits, (st.node_visits, node_visits)
     assert abs(st.tri_tests - tri_tests) <= 1e-4 * tri_tests, (st.tri_tests, tri_tests)
+
+
+def test_million_triangle_scene_against_brute_force(gpu_scenes, oracle):
+    """BASELINE configuration 5's scene (1.15 M triangles): the exhaustive binary64 test over every
+    triangle, on a sample of camera and scattered rays small enough for the CPU, bit for bit."""
+    s = gpu_scenes("spot_grid:14x14")
+    o = oracle.OracleScene.build("spot_grid:14x14")
+    assert o.counts()[0] == s.info().n_triangles == 1147777
+    co, cd = oracle.camera_rays(32, 18)
+    first = s.hit(co, cd)
+    hit = first["tri"] >= 0
+    rng = np.random.default_rng(4)
+    d2 = rng.normal(size=(int(hit.sum()), 3))
+    p2 = co[hit] + first["t"][hit, None] * cd[hit] + 1e-6 * d2
+    org, d = np.concatenate([co, p2]), np.concatenate([cd, d2])
+    got = s.hit(org, d)
+    want = o.hit(org, d, oracle.HIT_BRUTE, threads=16)
+    for f in ("obj", "tri", "t", "u", "v"):
+        assert got[f].tobytes() == want[f].tobytes(), f
+    assert (got["tri"] >= 0).sum() > 300

@@ -211,8 +211,11 @@ int rt_device_scene_upload_from(const rt_scene* s, rt_scene* target, int device)
   std::vector<TextureRec> trec(s->textures.size());
   for (size_t i = 0; i < s->textures.size(); ++i) {
     const uint8_t* px = nullptr;
-    if ((rc = upload_array(d, s->textures[i].rgba.data(), s->textures[i].rgba.size(), &px)) != RT_OK) return fail(rc);
-    trec[i] = TextureRec{px, s->textures[i].w, s->textures[i].h};
+    std::vector<uint8_t> tiled;
+    uint32_t blocks_x = 0;
+    rt_tile_texture(s->textures[i], &tiled, &blocks_x);
+    if ((rc = upload_array(d, tiled.data(), tiled.size(), &px)) != RT_OK) return fail(rc);
+    trec[i] = TextureRec{px, s->textures[i].w, s->textures[i].h, blocks_x};
   }
   if ((rc = upload_array(d, trec.data(), trec.size(), &d->k.tex)) != RT_OK) return fail(rc);
   d->k.root_ref = s->root_ref;

@@ -425,6 +425,20 @@ double rt_scene_box_pad(const rt_scene* s) {
   return extent * 9.5367431640625e-07;
 }
 
+// The tiled copy of a texture that goes to the device (layout: rt_types.h), on the builder's
+// threads; texels of the padding are zero and never addressed.
+void rt_tile_texture(const HostTexture& t, std::vector<uint8_t>* out, uint32_t* blocks_x) {
+  const uint32_t bx = (t.w + RT_TEX_BLOCK - 1) / RT_TEX_BLOCK, by = (t.h + RT_TEX_BLOCK - 1) / RT_TEX_BLOCK;
+  *blocks_x = bx;
+  out->assign((size_t)bx * by * RT_TEX_BLOCK * RT_TEX_BLOCK * 4u, 0);
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(t.rgba.data());
+  uint32_t* dst = reinterpret_cast<uint32_t*>(out->data());
+  parallel_ranges(t.h, 64, [&](size_t, size_t begin, size_t end) {
+    for (size_t y = begin; y < end; ++y)
+      for (uint32_t x = 0; x < t.w; ++x) dst[rt_texel_offset(x, (uint32_t)y, bx)] = src[y * t.w + x];
+  });
+}
+
 // dst[i] += src[i] on the builder's threads (the host-buffer render entry point adds a frame to the
 // caller's canvas with it).
 void rt_add_into(double* dst, const double* src, size_t n) {

@@ -445,7 +445,7 @@ __device__ __forceinline__ uint32_t texel_index(double x, uint32_t n) {
 __device__ __forceinline__ uchar4 fetch_texel(const TextureRec& t, double u, double v) {
   const uint32_t x = texel_index(u * (double)t.w, t.w);
   const uint32_t y = texel_index((1.0 - v) * (double)t.h, t.h);
-  return *reinterpret_cast<const uchar4*>(t.rgba + ((size_t)y * t.w + x) * 4);
+  return *reinterpret_cast<const uchar4*>(t.rgba + rt_texel_offset(x, y, t.blocks_x) * 4u);
 }
 
 __device__ __forceinline__ double bary(double a, double b, double c, double u, double v) {  // src/main.rs:741-745

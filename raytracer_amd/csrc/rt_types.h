@@ -58,10 +58,25 @@ struct alignas(16) SphereRec {
   int32_t pad[3];
 };
 
+// Textures are stored tiled in HBM: 32x32-texel blocks (4 KB) in row-major block order, each made
+// of 4x4 tiles of 8x8 texels (256 B = two cache lines), so that the texels of neighbouring hits
+// share lines and pages in both directions (a 20000-texel row is 80 KB: in row-major order the
+// texel one row down is 625 lines away). Width and height are padded up to whole blocks.
+#define RT_TEX_BLOCK 32u
 struct TextureRec {
-  const uint8_t* rgba;  // device pointer, row-major RGBA8, row 0 on top
+  const uint8_t* rgba;  // device pointer, RGBA8, tiled as above, row 0 on top
   uint32_t w, h;
+  uint32_t blocks_x;    // 32x32 blocks per row of blocks
 };
+// Offset, in texels, of texel (x, y) in the tiled layout.
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+static inline size_t rt_texel_offset(uint32_t x, uint32_t y, uint32_t blocks_x) {
+  const size_t block = (size_t)(y >> 5) * blocks_x + (x >> 5);
+  const uint32_t tile = ((y >> 3) & 3u) * 4u + ((x >> 3) & 3u);
+  return block * 1024u + tile * 64u + (y & 7u) * 8u + (x & 7u);
+}
 
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
 static_assert(sizeof(TriGeom) == 80, "TriGeom must be 80 bytes");
@@ -127,6 +142,7 @@ void rt_fill_leaf_records(rt_scene* s);
 double rt_scene_box_pad(const rt_scene* s);
 unsigned rt_build_threads();
 void rt_add_into(double* dst, const double* src, size_t n);
+void rt_tile_texture(const HostTexture& t, std::vector<uint8_t>* out, uint32_t* blocks_x);
 void rt_scene_centre_bounds(const rt_scene* s, double clo[3], double chi[3]);
 // rt_device.hip
 void rt_device_scene_free(DeviceScene* d);

@@ -265,7 +265,12 @@ static int group_render(rt_group* g, const rt_render_params* p, uint32_t split, 
       mp.tile_rank = i;
       mp.tile_ranks = n;
     }
-    threads.emplace_back(member_frame, g->members[i].get(), mp, sum_bytes);
+    try {
+      threads.emplace_back(member_frame, g->members[i].get(), mp, sum_bytes);
+    } catch (...) {  // no thread to be had: let the members already started finish, then report
+      for (std::thread& t : threads) t.join();
+      throw;
+    }
   }
   for (std::thread& t : threads) t.join();
   uint64_t rays = 0;

@@ -16,6 +16,7 @@
 #include <memory>
 #include <new>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -376,8 +377,14 @@ static void parallel_ranges(size_t n, size_t min_per_thread, F&& body) {
   }
   std::vector<std::thread> pool;
   pool.reserve(threads - 1);
-  for (size_t k = 1; k < threads; ++k) pool.emplace_back([&, k] { body(k, n * k / threads, n * (k + 1) / threads); });
+  size_t started = 1;  // pieces [started, threads) found no thread and run here instead
+  try {
+    for (; started < threads; ++started)
+      pool.emplace_back([&, started] { body(started, n * started / threads, n * (started + 1) / threads); });
+  } catch (const std::system_error&) {
+  }
   body((size_t)0, (size_t)0, n / threads);
+  for (size_t k = started; k < threads; ++k) body(k, n * k / threads, n * (k + 1) / threads);
   for (std::thread& t : pool) t.join();
 }
 

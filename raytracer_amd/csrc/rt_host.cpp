@@ -806,7 +806,7 @@ struct OwnedTriangles {
 static int scene_create(const rt_scene_desc* d, uint32_t tree, rt_scene** out, OwnedTriangles* owned);
 
 extern "C" int rt_scene_create_with(const rt_scene_desc* d, uint32_t tree, rt_scene** out) {
-  return scene_create(d, tree, out, nullptr);
+  return rt_guard("rt_scene_create", [&] { return scene_create(d, tree, out, nullptr); });
 }
 
 static int scene_create(const rt_scene_desc* d, uint32_t tree, rt_scene** out, OwnedTriangles* owned) {
@@ -931,7 +931,11 @@ extern "C" int rt_scene_from_objects(const rt_objects* objs, rt_scene** out) {
   return rt_scene_from_objects_with(objs, RT_TREE_HOST, out);
 }
 
+static int scene_from_objects(const rt_objects* objs, uint32_t tree, rt_scene** out);
 extern "C" int rt_scene_from_objects_with(const rt_objects* objs, uint32_t tree, rt_scene** out) {
+  return rt_guard("rt_scene_from_objects", [&] { return scene_from_objects(objs, tree, out); });
+}
+static int scene_from_objects(const rt_objects* objs, uint32_t tree, rt_scene** out) {
   if (!objs || !out) {
     rt_set_error("rt_scene_from_objects: null argument");
     return RT_ERR_INVALID;

@@ -211,14 +211,14 @@ extern "C" int rt_image_load_png(const char* path, rt_image** out) {
     rt_set_error("rt_image_load_png: null argument");
     return RT_ERR_INVALID;
   }
-  std::vector<uint8_t> file;
-  if (!read_file(path, &file)) {
-    rt_set_error("rt_image_load_png: cannot open %s", path);
-    return RT_ERR_IO;
-  }
   std::unique_ptr<rt_image> img(new (std::nothrow) rt_image());
   if (!img) return RT_ERR_OOM;
   try {
+    std::vector<uint8_t> file;
+    if (!read_file(path, &file)) {
+      rt_set_error("rt_image_load_png: cannot open %s", path);
+      return RT_ERR_IO;
+    }
     int rc = decode_png(file, path, img.get());
     if (rc != RT_OK) return rc;
   } catch (const std::bad_alloc&) {

@@ -10,7 +10,7 @@ SAN="-Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined -Xarch_host
 FLAGS="-O1 -g -std=c++17 -fPIC -ffp-contract=off -fno-fast-math"
 cd $R/raytracer_amd/csrc
 for f in rt_host.cpp rt_image.cpp rt_scenefile.cpp; do [ $B/$f.o -nt $f ] || /opt/rocm/bin/hipcc $FLAGS $SAN -c -o $B/$f.o $f; done
-for f in rt_device.hip rt_build.hip; do [ $B/$f.o -nt $f ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS $SAN -c -o $B/$f.o $f; done
+for f in rt_device.hip rt_build.hip rt_group.hip; do [ $B/$f.o -nt $f ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS $SAN -c -o $B/$f.o $f; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 $SAN -shared -o $B/librt_amd.so $B/*.o -lz
 /opt/rocm/bin/hipcc $FLAGS $SAN -o $B/host_sanitize $R/tools/host_sanitize.cpp -L$B -lrt_amd -Wl,-rpath,$B
 ASAN_OPTIONS=detect_leaks=1:protect_shadow_gap=0 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 $B/host_sanitize $R ${1:-300}

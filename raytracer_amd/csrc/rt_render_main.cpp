@@ -64,6 +64,14 @@ int main(int argc, char** argv) {
       return end && *end == '\0' && *dst >= 0;
     };
     bool ok = true;
+    if (a == "--help" || a == "-h") {
+      std::printf("usage: rt_render SCENE_FILE [-o OUT.png] [--width W] [--height H] [--spp S] [--its N] [--seed K] [--max-depth D]\n"
+                  "                 [--device I | --devices I,J,... [--split samples|tiles]] [--device-tree] [--progress]\n"
+                  "Renders a scene description file (grammar: include/rt_amd.h, examples: scenes/) on the GPU: N calls of S\n"
+                  "samples per pixel accumulate into one canvas, whose mean is written as a PNG. Options override the scene\n"
+                  "file's render statement.\n");
+      return 0;
+    }
     if (a == "-o" && i + 1 < argc) out_path = argv[++i];
     else if (a == "--width") ok = value(&o_w);
     else if (a == "--height") ok = value(&o_h);

@@ -38,6 +38,7 @@ FORM_NAMES = {
     "noregen": "single kernel, one thread per path",
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec
+L2_PEAK_GBS = 34500.0  # aggregate over the eight XCDs' L2s, measured
 FP64_PEAK_TFLOPS = 78.6
 FP32_PEAK_TFLOPS = 157.3
 
@@ -49,6 +50,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="sphere_floor_1080p_64spp", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the Spot 4K 256 spp frames timed after the main loop")
     ap.add_argument("--cpu-sample-spp", type=int, default=0, help="spp of the CPU baseline sample (0 = auto)")
     ap.add_argument("--split", default="samples", choices=["samples", "tiles", "samples_strong"],
                     help="N > 1: 'samples' = every rank renders the frame with its own samples (weak scaling, the default); "
@@ -222,12 +224,57 @@ def main():
     else:
         rays_all = float(rays_total)
 
+    # Which GPUs took part: every rank's device UUID, gathered, and the collective library's version.
+    prop0 = torch.cuda.get_device_properties(device)
+    my_id = f"{prop0.name} {getattr(prop0, 'uuid', '')} (rank {rank}, device {device})"
+    ids = [my_id]
+    if world > 1:
+        raw = torch.zeros(160, dtype=torch.uint8, device="cuda")
+        enc = torch.tensor(list(my_id.encode()[:160]), dtype=torch.uint8, device="cuda")
+        raw[: enc.numel()] = enc
+        gathered = [torch.zeros_like(raw) for _ in range(world)]
+        dist.all_gather(gathered, raw)
+        ids = [bytes(g.cpu().tolist()).rstrip(b"\0").decode(errors="replace") for g in gathered]
+    try:
+        coll = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception:
+        coll = None
+    ranks_seen = {"devices": ids, "distinct_devices": len({i.split(" (rank")[0] for i in ids}),
+                  "collective": None if world == 1 else f"{backend} (RCCL {coll})" if backend == "nccl" else backend}
+
+    # The second half of BASELINE.json's metric, "sec/frame Spot 4K 256spp": frames of that workload
+    # timed after the main loop, outside `value` (one GPU, default workload only).
+    secondary = None
+    if world == 1 and args.workload == "sphere_floor_1080p_64spp" and not args.no_secondary and args.form == "wave":
+        s_name, sW, sH, s_spp, _ = WORKLOADS["spot_4k_256spp"]
+        spot = scenes.build(s_name)
+        spot.upload(device)
+        s_canvas = torch.zeros((sH, sW, 3), dtype=torch.float64, device="cuda")
+        frames = 2
+        for k in range(1 + frames):  # one warm-up frame (allocates the work buffers), then the timed ones
+            if k == 1:
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+            spot.render_device(s_canvas.data_ptr(), rt.render_params(width=sW, height=sH, spp=s_spp, first_sample=k * s_spp, seed=0,
+                                                                     flags=_ffi.RT_FLAG_PIPELINE), stream)
+        spot.wait()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / frames
+        s_rays = spot.last_stats().rays / (1 + frames)
+        secondary = {"metric": "sec/frame Spot 4K 256spp", "value": round(dt, 5), "unit": "s", "higher_is_better": False,
+                     "workload": f"spot_4k_256spp: scene {s_name}, {sW}x{sH}, {s_spp} spp, depth cap 200",
+                     "frames_timed": frames, "mrays_per_s": round(s_rays / dt / 1e6, 1), "rays_per_frame": int(s_rays)}
+        del spot, s_canvas
+
     if rank == 0:
         value = rays_all / elapsed / 1e6
-        # Roofline of the dominant kernel (largest total time in the timed region). Algorithmic
-        # bytes per ray = 64 B per interior node visited + 192 B per triangle tested (72 B
-        # vertices + 72 B vertex normals + 48 B texture coordinates) + 48 B ray in + 40 B hit out,
-        # with that kernel's own per-ray means from the counting build.
+        # Roofline of the dominant kernel (largest total time in the timed region), against three
+        # candidate bounds; the headline fraction is the largest of them, i.e. the bound the kernel
+        # is closest to. Algorithmic work per ray, with that kernel's own per-ray means from the
+        # counting build: bytes = 64 B per interior node visited + 192 B per triangle tested (72 B
+        # vertices + 72 B vertex normals + 48 B texture coordinates) + 48 B ray in + 40 B hit out;
+        # flops = 24 per node visit (binary32 slab tests of two boxes) + 52 per triangle test + 30
+        # per sphere test (binary64).
         names = {0: "k_wave<false,0> (camera + trace + first bounce)", 1: "k_wave<false,1> (shade + trace, hit queue)",
                  2: "k_wave<false,2> (tail loop)", 3: "k_paths (single-kernel form)", 4: "k_resolve"}
         dom = max((k for k in timed if k != 4), key=lambda k: timed[k][0])
@@ -238,40 +285,90 @@ def main():
         if d_rays == 0:
             d_rays = rays_total
         bytes_per_ray = 64.0 * c_nodes / c_rays + 192.0 * c_tris / c_rays + 88.0
-        flops_per_ray = 24.0 * c_nodes / c_rays + 52.0 * c_tris / c_rays + 30.0 * per_ray["spheres"]
+        f32_flops_per_ray = 24.0 * c_nodes / c_rays
+        f64_flops_per_ray = 52.0 * c_tris / c_rays + 30.0 * per_ray["spheres"]
+        flops_per_ray = f32_flops_per_ray + f64_flops_per_ray
         launch_ms = d_ms / d_launches
+        launch_s = launch_ms * 1e-3
         rays_per_launch = d_rays / d_launches
-        achieved = bytes_per_ray * rays_per_launch / (launch_ms * 1e-3) / 1e9
         kernels = [
             {"kernel": names[k], "launches_per_frame": round(v[1] / args.steps, 2), "ms_per_frame": round(v[0] / args.steps, 4),
              "mrays_per_frame": round(v[2] / args.steps / 1e6, 3)}
             for k, v in sorted(timed.items())
         ]
         ms_resolve = [timed.get(4, [0.0, 1, 0])[0] / max(1, timed.get(4, [0.0, 1, 0])[1])]
-        # Counter-derived figures of the dominant kernel come from the committed rocprofv3 PMC
-        # passes of this same command (profiles/hbm_traffic.json); durations are measured live.
+        # Counter-derived figures of the dominant kernel (HBM bytes, VALU instructions) are replayed
+        # from the committed rocprofv3 PMC passes of this same command (profiles/hbm_traffic.json,
+        # stamped with the library revision they were taken on); durations are measured live.
         traffic = None
         valu_issue = None
+        counters_note = "none for this workload"
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tfile):
             try:
-                pmc = json.load(open(tfile)).get(args.workload, {}).get(names[dom].split(" ")[0], {})
+                tj = json.load(open(tfile))
+                pmc = tj.get(args.workload, {}).get(names[dom].split(" ")[0], {})
                 traffic = pmc.get("bytes_per_launch")
+                if traffic is not None:
+                    counters_note = f"replayed from profiles/hbm_traffic.json @{tj.get('_library_revision', 'unstamped')}"
                 if pmc.get("valu_wave_insts_per_launch"):
                     prop = torch.cuda.get_device_properties(device)
                     simds = 4 * prop.multi_processor_count
                     clock_ghz = (getattr(prop, "clock_rate", 0) or 0) / 1e6  # kHz -> GHz
                     if not (1.0 < clock_ghz <= 2.4):
                         clock_ghz = 2.4  # the MI355X's peak engine clock
-                    peak = simds * clock_ghz / 4.0  # a SIMD issues one wave64 VALU instruction per 4 cycles
-                    ach = pmc["valu_wave_insts_per_launch"] / (launch_ms * 1e-3) / 1e9
+                    peak = simds * clock_ghz / 4.0  # a SIMD issues one wave64 binary64 instruction per 4 cycles
+                    ach = pmc["valu_wave_insts_per_launch"] / launch_s / 1e9
                     valu_issue = {"achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instructions/s",
                                   "frac": round(ach / peak, 4), "lane_use": pmc.get("valu_lane_use"),
+                                  "insts_per_ray": round(pmc["valu_wave_insts_per_launch"] * 64.0 / rays_per_launch, 1),
                                   "note": "SQ_INSTS_VALU per launch (rocprofv3 PMC pass of this command, profiles/) over the live launch "
-                                          "duration, against 4 SIMDs x CUs x clock / 4; lane_use = share of the 64 lanes active per "
-                                          "VALU instruction"}
+                                          "duration, against 4 SIMDs x CUs x clock / 4 (the binary64 rate; binary32 and integer "
+                                          "instructions issue at twice that); lane_use = share of the 64 lanes active per VALU "
+                                          "instruction; insts_per_ray = lane-slots issued per ray"}
             except Exception:
                 traffic = None
+        # (i) VALU: time the algorithmic flops would take at the vector peaks (binary32 slab tests at
+        # the FP32 peak, triangle and sphere tests at the FP64 peak) over the launch time
+        valu_s = rays_per_launch * (f32_flops_per_ray / (FP32_PEAK_TFLOPS * 1e12) + f64_flops_per_ray / (FP64_PEAK_TFLOPS * 1e12))
+        ach_tflops = flops_per_ray * rays_per_launch / launch_s / 1e12
+        cand = {
+            "valu": {"achieved": round(ach_tflops, 4), "peak": round(ach_tflops * launch_s / valu_s, 2), "unit": "TFLOP/s",
+                     "frac": round(valu_s / launch_s, 5),
+                     "note": f"{f32_flops_per_ray:.1f} binary32 + {f64_flops_per_ray:.1f} binary64 algorithmic flops per ray; peak = this mix at "
+                             f"{FP32_PEAK_TFLOPS} / {FP64_PEAK_TFLOPS} TFLOP/s vector"},
+            # (iii) cache: the algorithmic bytes are served by L1/L2 (the scene fits), so they are priced
+            # against the aggregate L2 bandwidth
+            "l2": {"achieved": round(bytes_per_ray * rays_per_launch / launch_s / 1e9, 2), "peak": L2_PEAK_GBS, "unit": "GB/s",
+                   "frac": round(bytes_per_ray * rays_per_launch / launch_s / 1e9 / L2_PEAK_GBS, 5),
+                   "note": "algorithmic bytes of every node visit and triangle test over the launch time, against the aggregate L2 bandwidth"},
+        }
+        if traffic is not None:  # (ii) HBM: measured bytes per launch
+            cand["hbm"] = {"achieved": round(traffic / launch_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(traffic / launch_s / 1e9 / HBM_PEAK_GBS, 5),
+                           "note": "measured HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE) over the live launch time"}
+        bound = max(cand, key=lambda k: cand[k]["frac"])
+        roofline = {
+            "kernel": names[dom],
+            "bound": bound,
+            "achieved": cand[bound]["achieved"],
+            "peak": cand[bound]["peak"],
+            "unit": cand[bound]["unit"],
+            "frac": cand[bound]["frac"],
+            "traffic": traffic,
+            "counters": counters_note,
+            "launch_ms": round(launch_ms, 4),
+            "bytes_per_ray": round(bytes_per_ray, 1),
+            "flops_per_ray": round(flops_per_ray, 1),
+            "rays_per_launch": int(rays_per_launch),
+            "launches_per_frame": round(d_launches / args.steps, 2),
+            "resolve_ms": round(float(np.mean(ms_resolve)), 4),
+            "candidates": cand,
+            "valu_issue": valu_issue,
+            "note": "frac is the largest of the candidate fractions (VALU flops at the vector peaks, algorithmic bytes at the aggregate L2 "
+                    "bandwidth, measured HBM bytes at the HBM peak): the bound the kernel is closest to. The scene's tree and triangles stay "
+                    "in cache, so HBM carries only the sample and queue writes",
+        }
         out = {
             "metric": "Mrays/s (primary+secondary)",
             "value": round(value, 2),
@@ -304,32 +401,11 @@ def main():
             "rays_per_frame_per_gpu": int(rays_total / max(1, args.steps)),
             "per_ray": {k: round(v, 3) for k, v in per_ray.items()},
             "kernels": kernels,
-            "roofline": {
-                "kernel": names[dom],
-                "bound": "hbm",
-                "achieved": round(achieved, 2),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": traffic,
-                "launch_ms": round(launch_ms, 4),
-                "bytes_per_ray": round(bytes_per_ray, 1),
-                "rays_per_launch": int(rays_per_launch),
-                "launches_per_frame": round(d_launches / args.steps, 2),
-                "resolve_ms": round(float(np.mean(ms_resolve)), 4),
-                "note": "achieved counts the algorithmic bytes of every node visit and triangle test; this scene's tree and triangles "
-                        "stay in cache, so a fraction above what HBM could deliver means the kernel is not HBM bound (traffic = measured "
-                        "HBM bytes per launch); its VALU issue rate is what limits it (valu_issue)",
-                "valu_issue": valu_issue,
-                "valu": {
-                    "achieved_tflops": round(flops_per_ray * rays_per_launch / (launch_ms * 1e-3) / 1e12, 4),
-                    "flops_per_ray": round(flops_per_ray, 1),
-                    "peak_fp64_tflops": FP64_PEAK_TFLOPS,
-                    "peak_fp32_tflops": FP32_PEAK_TFLOPS,
-                    "note": "traversal slab tests are f32, triangle/sphere tests f64",
-                },
-            },
+            "roofline": roofline,
+            "ranks_seen": ranks_seen,
         }
+        if secondary is not None:
+            out["secondary"] = secondary
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported with the one-GPU line only
             out["cpu_baseline"] = cpu_baseline(scene_name, W, H, spp, args.cpu_sample_spp)
         print(json.dumps(out), flush=True)

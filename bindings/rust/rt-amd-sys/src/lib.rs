@@ -34,6 +34,7 @@ pub const RT_BUILD_PLOC: u32 = 1;
 pub const RT_BUILD_DEFAULT: u32 = RT_BUILD_PLOC;
 
 pub const RT_GROUP_MAX: u32 = 16;
+pub const RT_NOALLOC_SCRATCH_MIB: u32 = 320;
 pub const RT_SPLIT_SAMPLES: u32 = 0;
 pub const RT_SPLIT_TILES: u32 = 1;
 
@@ -210,6 +211,7 @@ extern "C" {
     pub fn rt_primary_hits(scene: *mut rt_scene, p: *const rt_render_params, obj: *mut i32, tri: *mut i32, t: *mut f64, u: *mut f64, v: *mut f64) -> c_int;
     pub fn rt_render_accumulate(scene: *mut rt_scene, p: *const rt_render_params, canvas: *mut f64, rays_out: *mut u64) -> c_int;
     pub fn rt_render_device(scene: *mut rt_scene, p: *const rt_render_params, device_canvas: *mut f64, stream: *mut c_void) -> c_int;
+    pub fn rt_render_device_noalloc(scene: *mut rt_scene, p: *const rt_render_params, device_canvas: *mut f64, stream: *mut c_void) -> c_int;
     pub fn rt_render_sum_f32_device(scene: *mut rt_scene, p: *const rt_render_params, device_sum: *mut f32, stream: *mut c_void) -> c_int;
     pub fn rt_scene_wait(scene: *mut rt_scene) -> c_int;
     pub fn rt_scene_stream_wait(scene: *mut rt_scene, stream: *mut c_void) -> c_int;

@@ -323,6 +323,22 @@ int rt_render_accumulate(rt_scene* scene, const rt_render_params* p, double* can
  * and rt_scene_wait synchronise with it), so it must outlive the scene's next call. */
 int rt_render_device(rt_scene* scene, const rt_render_params* p, double* device_canvas, void* stream);
 
+/* No counterpart in the reference. rt_render_device for callers that cannot allocate (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): the sample buffer,
+ * the running per-pixel totals, both ray queues and the counters come out of one static array in
+ * device memory, RT_NOALLOC_SCRATCH_MIB MiB per GPU, held by every GPU the library runs on until
+ * the process ends; the call makes no hipMalloc, hipFree, stream or event creation. The scene
+ * must already be uploaded (rt_scene_upload allocates); RT_ERR_NO_DEVICE otherwise. The array
+ * bounds the image: 24 + 248 bytes per pixel (296 with emissive materials) for one sample of
+ * every pixel of the call plus 18 MiB must fit, i.e. about 1 100 000 pixels per call (1280x720 fits);
+ * larger frames are RT_ERR_INVALID and are rendered as several calls over tile_size / tile_rank /
+ * tile_ranks, or with rt_render_device. More samples per pixel only take more passes. The
+ * canvas holds the same bits as after rt_render_device. RT_FLAG_PIPELINE and RT_FLAG_TIMING are
+ * ignored. All calls on one GPU share that GPU's array: calls that overlap in time on one GPU
+ * (two scenes, two streams, two host threads) race; one call at a time per GPU. */
+#define RT_NOALLOC_SCRATCH_MIB 320u
+int rt_render_device_noalloc(rt_scene* scene, const rt_render_params* p, double* device_canvas, void* stream);
+
 /* Sample-split rendering for several GPUs: device_sum[v][u][c] += sum (not mean) of this
  * call's samples, as binary32 — the buffer a sum-reduction over ranks then combines. */
 int rt_render_sum_f32_device(rt_scene* scene, const rt_render_params* p, float* device_sum, void* stream);

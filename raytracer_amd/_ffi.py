@@ -36,6 +36,7 @@ RT_BUILD_PLOC = 1
 RT_BUILD_DEFAULT = RT_BUILD_PLOC
 
 RT_GROUP_MAX = 16
+RT_NOALLOC_SCRATCH_MIB = 320
 RT_SPLIT_SAMPLES = 0
 RT_SPLIT_TILES = 1
 
@@ -194,6 +195,7 @@ SIGNATURES = {
     "rt_primary_hits": (C.c_int, [_P, C.POINTER(rt_render_params), _P, _P, _P, _P, _P]),
     "rt_render_accumulate": (C.c_int, [_P, C.POINTER(rt_render_params), _P, C.POINTER(C.c_uint64)]),
     "rt_render_device": (C.c_int, [_P, C.POINTER(rt_render_params), _P, _P]),
+    "rt_render_device_noalloc": (C.c_int, [_P, C.POINTER(rt_render_params), _P, _P]),
     "rt_render_sum_f32_device": (C.c_int, [_P, C.POINTER(rt_render_params), _P, _P]),
     "rt_scene_wait": (C.c_int, [_P]),
     "rt_scene_stream_wait": (C.c_int, [_P, _P]),

@@ -62,6 +62,7 @@ struct DeviceScene {
   double* queue_rad[2] = {nullptr, nullptr};  // emitted radiance carried per queue entry
   size_t queue_rad_bytes[2] = {0, 0};
   unsigned long long* counters = nullptr;       // RT_SHARDS lines
+  unsigned long long* cur_counters = nullptr;   // the lines the last call counted in (counters, or the static scratch's)
   unsigned long long* host_counters = nullptr;  // pinned mirror
   // Overlapped tails: when a call runs in several sample chunks, the thin tail of long paths of
   // one chunk (and that chunk's resolve) runs on a side stream while the next chunk starts.
@@ -110,6 +111,52 @@ struct DeviceScene {
       return RT_ERR_HIP;                                                                       \
     }                                                                                          \
   } while (0)
+
+// ------------------------------------------------------------------------------------------
+// Static work memory for rt_render_device_noalloc: callers that may not allocate (code under
+// graph capture, serving loops, harnesses that forbid hipMalloc) get their sample buffer, ray
+// queues and counters out of this array instead of hipMalloc'ed buffers. Every GPU the library
+// runs on holds its own copy of the array, at its own address, until the process ends; the
+// array's name is only a host-side handle, so the address is asked for once per device and kept.
+// ------------------------------------------------------------------------------------------
+#define RT_SCRATCH_BYTES ((size_t)RT_NOALLOC_SCRATCH_MIB << 20)
+#define RT_SCRATCH_MAX_DEVICES 64
+static __device__ __align__(256) unsigned char scratch[RT_SCRATCH_BYTES];
+static unsigned char* g_scratch_ptr[RT_SCRATCH_MAX_DEVICES] = {};
+
+// Address of `device`'s copy of the array (the device is made current). Called when a scene is
+// uploaded, so that the render call itself finds the address already there.
+static int scratch_address(int device, unsigned char** out) {
+  if (device < 0 || device >= RT_SCRATCH_MAX_DEVICES) {
+    rt_set_error("device %d is beyond the %d devices the static work memory is tracked for", device, RT_SCRATCH_MAX_DEVICES);
+    return RT_ERR_INVALID;
+  }
+  if (!g_scratch_ptr[device]) {
+    HIP_TRY(hipSetDevice(device));
+    void* p = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) {
+      rt_set_error("hipGetSymbolAddress returned no address for the static work memory on device %d", device);
+      return RT_ERR_HIP;
+    }
+    g_scratch_ptr[device] = static_cast<unsigned char*>(p);
+  }
+  *out = g_scratch_ptr[device];
+  return RT_OK;
+}
+
+// Bump allocation inside the static array (256-byte granules).
+struct Arena {
+  unsigned char* base;
+  size_t bytes;
+  size_t used;
+};
+static void* arena_take(Arena* a, size_t n) {
+  const size_t at = (a->used + 255u) & ~(size_t)255u;
+  if (at + n > a->bytes) return nullptr;
+  a->used = at + n;
+  return a->base + at;
+}
 
 void rt_device_scene_free(DeviceScene* d) {
   if (!d) return;
@@ -234,6 +281,10 @@ int rt_device_scene_upload_from(const rt_scene* s, rt_scene* target, int device)
     return fail(RT_ERR_HIP);
   }
   (void)hipMemset(d->tail_counters, 0, RT_COUNTER_BYTES);
+  {
+    unsigned char* sp = nullptr;
+    if ((rc = scratch_address(device, &sp)) != RT_OK) return fail(rc);
+  }
   if (hipHostMalloc((void**)&d->host_counters, RT_COUNTER_BYTES, hipHostMallocDefault) != hipSuccess) {
     rt_set_error("rt_scene_upload: hipHostMalloc of the counter mirror failed");
     return fail(RT_ERR_HIP);
@@ -278,7 +329,7 @@ static void sum_lines(const unsigned long long* lines, CounterSums* sums) {
     for (int w = 0; w < CNT_N; ++w) sums->w[w] += lines[(size_t)s * RT_LINE_WORDS + w];
 }
 static int read_counters(DeviceScene* d, hipStream_t stream, CounterSums* sums) {
-  HIP_TRY(hipMemcpyAsync(d->host_counters, d->counters, RT_COUNTER_BYTES, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipMemcpyAsync(d->host_counters, d->cur_counters ? d->cur_counters : d->counters, RT_COUNTER_BYTES, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   std::memset(sums, 0, sizeof *sums);
   sum_lines(d->host_counters, sums);
@@ -1080,7 +1131,10 @@ static uint64_t queue_entries(uint32_t n_paths) {
   return (uint64_t)n_seg * ((blocks + n_seg - 1) / n_seg) * RT_BLOCK;
 }
 
-static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas, float* d_sum, hipStream_t stream, const char* who) {
+// `arena` != nullptr: the call takes every work buffer out of the arena (the static work memory)
+// and makes no allocating call: no second sample buffer, no side stream, no events.
+static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas, float* d_sum, hipStream_t stream, const char* who,
+                       Arena* arena = nullptr) {
   int rc = require_device(s, who);
   if (rc != RT_OK) return rc;
   if ((rc = check_params(p, who)) != RT_OK) return rc;
@@ -1093,10 +1147,21 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
   // RT_FLAG_PIPELINE: the call may return with its tail and resolve still queued on the side
   // stream, so that the next call's first stage overlaps them. Consecutive pipelined calls on one
   // stream form a run whose counters, launch log and timing accumulate.
-  const bool pipeline = (p->flags & RT_FLAG_PIPELINE) != 0 && !mega;
+  const bool pipeline = (p->flags & RT_FLAG_PIPELINE) != 0 && !mega && !arena;
   const bool continuing = pipeline && d->run_open && d->last_stream_valid && d->last_stream == stream;
   if (!continuing) {
     if (d->run_open && (rc = finish_run(d)) != RT_OK) return rc;  // an earlier run still holds the side stream
+    // An earlier call may still have kernels queued on another stream; they read the counters and
+    // work buffers this call is about to reset.
+    if (d->last_stream_valid && d->last_stream != stream) {
+      if (arena) {
+        HIP_TRY(hipStreamSynchronize(d->last_stream));
+      } else {
+        if (!d->ev_join[0]) HIP_TRY(hipEventCreateWithFlags(&d->ev_join[0], hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(d->ev_join[0], d->last_stream));
+        HIP_TRY(hipStreamWaitEvent(stream, d->ev_join[0], 0));
+      }
+    }
     d->have_timing = false;
     d->launches.clear();
     d->pending.clear();
@@ -1105,9 +1170,18 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
     d->side_used = false;
     std::memset(d->prev_w, 0, sizeof d->prev_w);
     std::memset(&d->timing, 0, sizeof d->timing);
-    HIP_TRY(hipMemsetAsync(d->counters, 0, RT_COUNTER_BYTES, stream));
+    d->cur_counters = d->counters;
+    if (arena) {
+      d->cur_counters = static_cast<unsigned long long*>(arena_take(arena, RT_COUNTER_BYTES));
+      if (!d->cur_counters) {
+        rt_set_error("%s: the static work memory is smaller than the counters", who);
+        return RT_ERR_INVALID;
+      }
+    }
+    HIP_TRY(hipMemsetAsync(d->cur_counters, 0, RT_COUNTER_BYTES, stream));
     HIP_TRY(hipMemsetAsync(d->tail_counters, 0, RT_COUNTER_BYTES, stream));
   }
+  unsigned long long* const counters = d->cur_counters;
   d->last_stream = stream;
   d->last_stream_valid = true;
   d->run_open = pipeline;
@@ -1115,7 +1189,7 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
 
   const TileMap tm = make_tilemap(p);
   if (tm.n_tiles == 0) return RT_OK;
-  const bool timing = (p->flags & RT_FLAG_TIMING) != 0;
+  const bool timing = (p->flags & RT_FLAG_TIMING) != 0 && !arena;  // timing takes events from a growing pool
   const bool count = (p->flags & RT_FLAG_COUNT_WORK) != 0;
   const bool regen = (p->flags & RT_FLAG_NO_REGEN) == 0;
   const bool emission = d->k.has_emission != 0;
@@ -1127,7 +1201,20 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
   // Budget of the work buffers: RT_WORK_BUFFER_MIB, else 192 GiB of the MI355X's 288 GB, and in
   // any case no more than four fifths of what is free (counting what the scene already holds).
   size_t budget = env_mib("RT_WORK_BUFFER_MIB", 196608) << 20;
-  {
+  if (arena) {
+    // what is left of the array, less the per-pixel totals of a call in several chunks and the
+    // round-up of the queues to whole blocks per segment (at most RT_SHARDS blocks each) and of
+    // every piece to 256 bytes
+    const size_t left = arena->bytes - arena->used;
+    const size_t fixed = (size_t)n_pix * 24u + 2u * (size_t)RT_SHARDS * RT_BLOCK * (sizeof(QueueRec) + 24u) + 8u * 256u;
+    if (left < fixed + (size_t)n_pix * per_path) {
+      rt_set_error("%s: %llu pixels need %llu bytes of work memory per sample, the static work memory holds %llu (RT_NOALLOC_SCRATCH_MIB = %u); "
+                   "render the image in tiles (tile_size, tile_rank, tile_ranks) or use rt_render_device",
+                   who, (unsigned long long)n_pix, (unsigned long long)(fixed + n_pix * per_path), (unsigned long long)left, (unsigned)RT_NOALLOC_SCRATCH_MIB);
+      return RT_ERR_INVALID;
+    }
+    budget = left - fixed;
+  } else {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
       const size_t held = d->samples_bytes + d->totals_bytes + d->queue_bytes[0] + d->queue_bytes[1] + d->queue_rad_bytes[0] + d->queue_rad_bytes[1];
@@ -1143,19 +1230,47 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
   // A call in several chunks overlaps each chunk's tail with the next chunk, and a pipelined call
   // its last tail with the next call; both take a second sample buffer (24 B per path more).
   const char* no_overlap = std::getenv("RT_NO_OVERLAP");
-  bool overlap = !mega && (pipeline || p->spp > chunk64) && !(no_overlap && *no_overlap);
+  bool overlap = !mega && !arena && (pipeline || p->spp > chunk64) && !(no_overlap && *no_overlap);
   if (overlap) chunk64 = std::max<uint64_t>(1, std::min<uint64_t>(budget / (n_pix * (per_path + 24u)), 0xfff00000ull / n_pix));
   const uint32_t chunk = (uint32_t)std::min<uint64_t>(p->spp, chunk64);
   const uint32_t n_chunks = (p->spp + chunk - 1) / chunk;
   overlap = overlap && (n_chunks > 1 || pipeline);
   const uint64_t cap = n_pix * chunk;  // paths per launch
-  if ((rc = ensure_bytes((void**)&d->samples, &d->samples_bytes, (size_t)cap * 24u * (overlap ? 2u : 1u))) != RT_OK) return rc;
-  if (n_chunks > 1 && (rc = ensure_bytes((void**)&d->totals, &d->totals_bytes, (size_t)n_pix * 24u)) != RT_OK) return rc;
-  if (!mega) {
-    const uint64_t qe = queue_entries((uint32_t)cap);
+  double* samples_base = nullptr;
+  double* totals = nullptr;
+  void* queue[2] = {nullptr, nullptr};
+  double* queue_rad[2] = {nullptr, nullptr};
+  size_t samples_half = 0;  // doubles from one sample buffer to the other (overlap)
+  if (arena) {
+    bool ok = (samples_base = static_cast<double*>(arena_take(arena, (size_t)cap * 24u))) != nullptr;
+    if (n_chunks > 1) ok = ok && (totals = static_cast<double*>(arena_take(arena, (size_t)n_pix * 24u))) != nullptr;
+    if (!mega) {
+      const uint64_t qe = queue_entries((uint32_t)cap);
+      for (int q = 0; q < 2; ++q) {
+        ok = ok && (queue[q] = arena_take(arena, (size_t)qe * sizeof(QueueRec))) != nullptr;
+        if (emission) ok = ok && (queue_rad[q] = static_cast<double*>(arena_take(arena, (size_t)qe * 24u))) != nullptr;
+      }
+    }
+    if (!ok) {
+      rt_set_error("%s: internal error: the static work memory ran out", who);
+      return RT_ERR_INVALID;
+    }
+  } else {
+    if ((rc = ensure_bytes((void**)&d->samples, &d->samples_bytes, (size_t)cap * 24u * (overlap ? 2u : 1u))) != RT_OK) return rc;
+    if (n_chunks > 1 && (rc = ensure_bytes((void**)&d->totals, &d->totals_bytes, (size_t)n_pix * 24u)) != RT_OK) return rc;
+    if (!mega) {
+      const uint64_t qe = queue_entries((uint32_t)cap);
+      for (int q = 0; q < 2; ++q) {
+        if ((rc = ensure_bytes(&d->queue[q], &d->queue_bytes[q], (size_t)qe * sizeof(QueueRec))) != RT_OK) return rc;
+        if (emission && (rc = ensure_bytes((void**)&d->queue_rad[q], &d->queue_rad_bytes[q], (size_t)qe * 24u)) != RT_OK) return rc;
+      }
+    }
+    samples_base = d->samples;
+    totals = d->totals;
+    samples_half = d->samples_bytes / 16u;
     for (int q = 0; q < 2; ++q) {
-      if ((rc = ensure_bytes(&d->queue[q], &d->queue_bytes[q], (size_t)qe * sizeof(QueueRec))) != RT_OK) return rc;
-      if (emission && (rc = ensure_bytes((void**)&d->queue_rad[q], &d->queue_rad_bytes[q], (size_t)qe * 24u)) != RT_OK) return rc;
+      queue[q] = d->queue[q];
+      queue_rad[q] = d->queue_rad[q];
     }
   }
   const uint32_t tail_threshold = (uint32_t)env_mib("RT_TAIL_THRESHOLD", 262144);
@@ -1260,7 +1375,7 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
     // last chunk of a pipelined call.
     const bool handoff = overlap && (c + 1 < n_chunks || pipeline);
     const int par = overlap ? (int)(d->chunk_seq++ & 1u) : 0;
-    double* const samples = d->samples + (overlap ? (size_t)par * (d->samples_bytes / 16u) : 0u);
+    double* const samples = samples_base + (overlap ? (size_t)par * samples_half : 0u);
     // this parity's sample buffer and tail input were last read two chunks ago on the side stream
     if (overlap && d->resolved_valid[par]) HIP_TRY(hipStreamWaitEvent(stream, d->ev_resolved[par], 0));
     hipStream_t resolve_on = stream;
@@ -1269,15 +1384,15 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
       uint32_t grid = blocks_all;
       if (regen) {
         grid = std::min<uint32_t>(blocks_all, (uint32_t)cus * 8u * (256u / RT_BLOCK));  // 32 waves per CU
-        HIP_TRY(hipMemsetAsync(d->counters + CNT_WORK, 0, sizeof(unsigned long long), stream));
+        HIP_TRY(hipMemsetAsync(counters + CNT_WORK, 0, sizeof(unsigned long long), stream));
       }
       if ((rc = begin_launch(3, pp.n_paths, stream)) != RT_OK) return rc;
       if (regen) {
-        if (count) hipLaunchKernelGGL((k_paths<true, true>), dim3(grid), dim3(RT_BLOCK), lds, stream, d->k, pp, samples, d->counters);
-        else hipLaunchKernelGGL((k_paths<false, true>), dim3(grid), dim3(RT_BLOCK), lds, stream, d->k, pp, samples, d->counters);
+        if (count) hipLaunchKernelGGL((k_paths<true, true>), dim3(grid), dim3(RT_BLOCK), lds, stream, d->k, pp, samples, counters);
+        else hipLaunchKernelGGL((k_paths<false, true>), dim3(grid), dim3(RT_BLOCK), lds, stream, d->k, pp, samples, counters);
       } else {
-        if (count) hipLaunchKernelGGL((k_paths<true, false>), dim3(grid), dim3(RT_BLOCK), lds, stream, d->k, pp, samples, d->counters);
-        else hipLaunchKernelGGL((k_paths<false, false>), dim3(grid), dim3(RT_BLOCK), lds, stream, d->k, pp, samples, d->counters);
+        if (count) hipLaunchKernelGGL((k_paths<true, false>), dim3(grid), dim3(RT_BLOCK), lds, stream, d->k, pp, samples, counters);
+        else hipLaunchKernelGGL((k_paths<false, false>), dim3(grid), dim3(RT_BLOCK), lds, stream, d->k, pp, samples, counters);
       }
       if ((rc = end_launch(stream)) != RT_OK) return rc;
     } else {
@@ -1286,13 +1401,13 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
       const uint32_t seg_cap = ((blocks_all + n_seg - 1) / n_seg) * RT_BLOCK;
       QueueView qv[2];
       for (int q = 0; q < 2; ++q)
-        qv[q] = QueueView{(float4*)d->queue[q], n_seg * seg_cap, d->queue_rad[q], seg_cap, (uint32_t)(q ? CNT_Q1 : CNT_Q0), (uint32_t)(q ? CNT_R1 : CNT_R0)};
+        qv[q] = QueueView{(float4*)queue[q], n_seg * seg_cap, queue_rad[q], seg_cap, (uint32_t)(q ? CNT_Q1 : CNT_Q0), (uint32_t)(q ? CNT_R1 : CNT_R0)};
       const size_t line_bytes = RT_LINE_WORDS * sizeof(unsigned long long);
       // the four counts of every line start at zero (adjacent words)
-      HIP_TRY(hipMemset2DAsync(d->counters + CNT_Q0, line_bytes, 0, 4 * sizeof(unsigned long long), RT_SHARDS, stream));
+      HIP_TRY(hipMemset2DAsync(counters + CNT_Q0, line_bytes, 0, 4 * sizeof(unsigned long long), RT_SHARDS, stream));
       if ((rc = begin_launch(0, pp.n_paths, stream)) != RT_OK) return rc;
-      if (count) hipLaunchKernelGGL((k_wave<true, 0>), dim3(blocks_all), dim3(RT_BLOCK), lds, stream, d->k, pp, qv[0], qv[0], n_seg, 0u, samples, d->counters);
-      else hipLaunchKernelGGL((k_wave<false, 0>), dim3(blocks_all), dim3(RT_BLOCK), lds, stream, d->k, pp, qv[0], qv[0], n_seg, 0u, samples, d->counters);
+      if (count) hipLaunchKernelGGL((k_wave<true, 0>), dim3(blocks_all), dim3(RT_BLOCK), lds, stream, d->k, pp, qv[0], qv[0], n_seg, 0u, samples, counters);
+      else hipLaunchKernelGGL((k_wave<false, 0>), dim3(blocks_all), dim3(RT_BLOCK), lds, stream, d->k, pp, qv[0], qv[0], n_seg, 0u, samples, counters);
       if ((rc = end_launch(stream)) != RT_OK) return rc;
       int cur = 0;
       for (;;) {
@@ -1321,7 +1436,7 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
           // compact what is left into this parity's tail segment; the side stream takes it from there
           const QueueView tv{(float4*)d->tail_in[par], tail_cap, d->tail_rad[par], tail_cap, (uint32_t)(par ? CNT_Q1 : CNT_Q0), (uint32_t)(par ? CNT_R1 : CNT_R0)};
           HIP_TRY(hipMemsetAsync(d->tail_counters + tv.hit_word, 0, 2 * sizeof(unsigned long long), stream));
-          hipLaunchKernelGGL(k_gather, grid, dim3(RT_BLOCK), 0, stream, qv[cur], tv, hit_blocks, (int)emission, d->counters, d->tail_counters);
+          hipLaunchKernelGGL(k_gather, grid, dim3(RT_BLOCK), 0, stream, qv[cur], tv, hit_blocks, (int)emission, counters, d->tail_counters);
           HIP_TRY(hipGetLastError());
           HIP_TRY(hipEventRecord(d->ev_gathered[par], stream));
           HIP_TRY(hipStreamWaitEvent(d->side, d->ev_gathered[par], 0));
@@ -1342,8 +1457,8 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
         }
         if (n_in <= tail_threshold) {
           if ((rc = begin_launch(2, (uint32_t)n_in, stream)) != RT_OK) return rc;
-          if (count) hipLaunchKernelGGL((k_wave<true, 2>), grid, dim3(RT_BLOCK), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, hit_blocks, samples, d->counters);
-          else hipLaunchKernelGGL((k_wave<false, 2>), grid, dim3(RT_BLOCK), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, hit_blocks, samples, d->counters);
+          if (count) hipLaunchKernelGGL((k_wave<true, 2>), grid, dim3(RT_BLOCK), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, hit_blocks, samples, counters);
+          else hipLaunchKernelGGL((k_wave<false, 2>), grid, dim3(RT_BLOCK), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, hit_blocks, samples, counters);
           if ((rc = end_launch(stream)) != RT_OK) return rc;
           if (count || timing) {
             if ((rc = read_counters(d, stream, &now)) != RT_OK) return rc;
@@ -1351,10 +1466,10 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
           }
           break;
         }
-        HIP_TRY(hipMemset2DAsync(d->counters + (nxt ? CNT_Q1 : CNT_Q0), line_bytes, 0, 2 * sizeof(unsigned long long), RT_SHARDS, stream));
+        HIP_TRY(hipMemset2DAsync(counters + (nxt ? CNT_Q1 : CNT_Q0), line_bytes, 0, 2 * sizeof(unsigned long long), RT_SHARDS, stream));
         if ((rc = begin_launch(1, (uint32_t)n_in, stream)) != RT_OK) return rc;
-        if (count) hipLaunchKernelGGL((k_wave<true, 1>), grid, dim3(RT_BLOCK), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, hit_blocks, samples, d->counters);
-        else hipLaunchKernelGGL((k_wave<false, 1>), grid, dim3(RT_BLOCK), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, hit_blocks, samples, d->counters);
+        if (count) hipLaunchKernelGGL((k_wave<true, 1>), grid, dim3(RT_BLOCK), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, hit_blocks, samples, counters);
+        else hipLaunchKernelGGL((k_wave<false, 1>), grid, dim3(RT_BLOCK), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, hit_blocks, samples, counters);
         if ((rc = end_launch(stream)) != RT_OK) return rc;
         cur = nxt;
       }
@@ -1370,7 +1485,7 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
     if (overlap && !handoff && d->resolved_valid[par ^ 1]) HIP_TRY(hipStreamWaitEvent(stream, d->ev_resolved[par ^ 1], 0));
     const uint32_t rgrid = (uint32_t)((n_pix + RT_BLOCK - 1) / RT_BLOCK);
     if ((rc = begin_launch(4, (uint32_t)n_pix, resolve_on)) != RT_OK) return rc;
-    hipLaunchKernelGGL(k_resolve, dim3(rgrid), dim3(RT_BLOCK), 0, resolve_on, tm, samples, pp.n_paths, pp.spp, d->totals,
+    hipLaunchKernelGGL(k_resolve, dim3(rgrid), dim3(RT_BLOCK), 0, resolve_on, tm, samples, pp.n_paths, pp.spp, totals,
                        (int)(c == 0), (int)(c + 1 == n_chunks), divisor, d_canvas, d_sum);
     if ((rc = end_launch(resolve_on)) != RT_OK) return rc;
     if (handoff) {
@@ -1408,6 +1523,22 @@ extern "C" int rt_render_device(rt_scene* s, const rt_render_params* p, double* 
 }
 static int rt_render_device_body(rt_scene* s, const rt_render_params* p, double* device_canvas, void* stream) {
   return render_impl(s, p, device_canvas, nullptr, (hipStream_t)stream, "rt_render_device");
+}
+
+// The same call as rt_render_device with every work buffer (sample buffer, running totals, both
+// ray queues, counters) taken out of the static work memory: no hipMalloc, hipFree, stream or
+// event creation. The scene must have been uploaded before (rt_scene_upload allocates).
+extern "C" int rt_render_device_noalloc(rt_scene* s, const rt_render_params* p, double* device_canvas, void* stream) {
+  return rt_guard("rt_render_device_noalloc", [&] {
+    if (!s || !s->dev) {
+      rt_set_error("rt_render_device_noalloc: the scene has not been uploaded (rt_scene_upload allocates; this call does not)");
+      return s ? RT_ERR_NO_DEVICE : RT_ERR_INVALID;
+    }
+    Arena arena{nullptr, RT_SCRATCH_BYTES, 0};
+    int rc = scratch_address(s->dev->device, &arena.base);
+    if (rc != RT_OK) return rc;
+    return render_impl(s, p, device_canvas, nullptr, (hipStream_t)stream, "rt_render_device_noalloc", &arena);
+  });
 }
 
 static int rt_render_sum_f32_device_body(rt_scene* s, const rt_render_params* p, float* device_sum, void* stream);
@@ -1485,6 +1616,7 @@ static int rt_trace_body(rt_scene* s, const double* org3, const double* dir3, si
   rt_hit* d_hit = (rt_hit*)(d_dir + n * 3);
   HIP_TRY(hipMemcpy(d_org, org3, ray_bytes, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(d_dir, dir3, ray_bytes, hipMemcpyHostToDevice));
+  d->cur_counters = d->counters;
   HIP_TRY(hipMemset(d->counters, 0, RT_COUNTER_BYTES));
   const uint32_t grid = (uint32_t)((n + RT_BLOCK - 1) / RT_BLOCK);
   hipLaunchKernelGGL((k_trace<true>), dim3(grid), dim3(RT_BLOCK), stack_lds_bytes(d), nullptr, d->k, d_org, d_dir, n, d_hit, d->counters);
@@ -1524,6 +1656,7 @@ static int rt_primary_hits_body(rt_scene* s, const rt_render_params* p, int32_t*
   q.flags |= RT_FLAG_NO_JITTER;
   q.dof_strength = 0.0;
   CameraK cam = make_camera(&q);
+  d->cur_counters = d->counters;
   HIP_TRY(hipMemset(d->counters, 0, RT_COUNTER_BYTES));
   const uint32_t grid = (uint32_t)((npix + RT_BLOCK - 1) / RT_BLOCK);
   hipLaunchKernelGGL(k_primary, dim3(grid), dim3(RT_BLOCK), stack_lds_bytes(d), nullptr, d->k, cam, d_obj, d_tri, d_t, d_u, d_v, d->counters);

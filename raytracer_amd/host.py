@@ -295,6 +295,11 @@ class Scene:
     def render_device(self, device_canvas_ptr, params, stream=None):
         check(lib.rt_render_device(self._h, C.byref(params), C.c_void_p(device_canvas_ptr), C.c_void_p(stream or 0)), "rt_render_device")
 
+    def render_device_noalloc(self, device_canvas_ptr, params, stream=None):
+        """render_device out of the library's static work memory: allocates nothing; the scene must
+        already be uploaded and the image is bounded (see rt_render_device_noalloc)."""
+        check(lib.rt_render_device_noalloc(self._h, C.byref(params), C.c_void_p(device_canvas_ptr), C.c_void_p(stream or 0)), "rt_render_device_noalloc")
+
     def render_sum_f32_device(self, device_sum_ptr, params, stream=None):
         check(lib.rt_render_sum_f32_device(self._h, C.byref(params), C.c_void_p(device_sum_ptr), C.c_void_p(stream or 0)), "rt_render_sum_f32_device")
 

@@ -42,6 +42,7 @@ using namespace rtk;
 #define RT_SHARDS 1024     /* counter lines; also the most queue segments a launch uses */
 #define RT_LINE_WORDS 16   /* 64-bit words per line (128 B)                             */
 #define RT_WORK_BATCH 1024 /* path indices a wave takes from the work counter at a time */
+#define RT_LONG_STEPS_DEFAULT 8u /* node visits from which a ray counts as long (see k_wave) */
 // words of a line
 enum { CNT_RAYS = 0, CNT_NODES, CNT_TRIS, CNT_SPHERES, CNT_SHADED, CNT_PATHS, CNT_Q0, CNT_R0, CNT_Q1, CNT_R1, CNT_WORK, CNT_WI_INNER, CNT_WI_LEAF, CNT_WI_REJECT, CNT_WAVES, CNT_N };
 #define RT_COUNTER_BYTES ((size_t)RT_SHARDS * RT_LINE_WORDS * sizeof(unsigned long long))
@@ -572,7 +573,7 @@ struct PathParams {
   uint32_t first_sample;  // stream index of this launch's sample 0
   int32_t max_depth;
   uint32_t fuse_bounces;  // bounces the first wavefront stage follows before it queues its hits
-  uint32_t short_steps;   // node visits a scattered ray gets before it is queued as a long ray
+  uint32_t long_steps;    // a hit found after at least this many node visits is queued in the back run
 };
 
 // Path index -> pixel and sample; starts the path (camera ray, src/main.rs:995-1013).
@@ -704,23 +705,20 @@ __global__ __launch_bounds__(RT_BLOCK) void k_paths(SceneK sc, PathParams pp, do
 // ------------------------------------------------------------------------------------------
 // Wavefront form of the same loop: launches over compacted queues of the paths still alive.
 //
-// What costs a wave most is one lane walking deep into the tree while the other 63 wait: most
-// scattered rays leave the scene within a few node visits, a minority needs dozens. So a
-// scattered ray is first traced for at most `short_steps` node visits. If that settles it, the
-// lane goes on as before (miss: add throughput * sky, write the sample; hit: queue the hit).
-// If not, the ray itself is queued, and a later launch traces the long rays together, in waves
-// that are all long. Two kinds of queue record, one buffer:
-//   hit record  (a hit waiting to be shaded)  appended at the front of a segment,
-//   ray record  (a ray waiting to be traced)  appended at the back of the same segment.
+// Stage 0 starts every path (camera ray) and traces it — primary rays of one 8x8 tile walk the same
+// nodes — then shades and traces the first `fuse_bounces` bounces itself: a wave's primary rays hit
+// one surface or all miss, so compacting them first would buy nothing and cost a queue record per
+// hit. Stage 1 runs over a queue of hit records: shade, trace the scattered ray, append the next
+// hit to the other queue. Stage 2 is stage 1 that keeps every path until it ends, for the thin
+// tail of long paths. Every path writes its sample exactly once, into its own slot, so results do
+// not depend on queue order.
 //
-// Stage 0 starts every path (camera ray) and traces it to the end — primary rays of one 8x8
-// tile walk the same nodes — then shades and short-traces the first `fuse_bounces` bounces
-// itself: a wave's primary rays hit one surface or all miss, so compacting them first would buy
-// nothing and cost a queue record per hit. Stage 1 runs over a queue: blocks of hit records
-// shade and short-trace, blocks of ray records trace to the end; both append to the other
-// queue. Stage 2 is stage 1 that keeps every path until it ends, for the thin tail of long
-// paths. Every path writes its sample exactly once, into its own slot, so results do not
-// depend on queue order.
+// What costs a wave most is one lane walking deep into the tree while the other 63 wait: most
+// scattered rays leave the scene within a few node visits, a minority (rays that start inside or
+// next to a dense mesh) needs dozens, and a path whose last ray was long will mostly cast a long
+// one again. So a hit is filed by the cost of the ray that found it: hits found within
+// `long_steps` node visits at the front of a segment, the others at its back, and the next launch
+// runs the two runs in separate waves.
 //
 // A queue is n_seg segments of seg_cap records; segment s keeps its two counts in counter line
 // s. Stage 0 block b appends to segment b % n_seg; later stages run on a (n_seg, blocks) grid
@@ -729,13 +727,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_paths(SceneK sc, PathParams pp, do
 // blocks spread over all counter lines.
 // ------------------------------------------------------------------------------------------
 struct alignas(16) QueueRec {  // 112 B
-  double hit_pos[3];  // hit record: the hit point; ray record: the ray origin
-  double dir[3];      // hit record: the direction the path arrived along; ray record: the ray
+  double hit_pos[3];  // the hit point
+  double dir[3];      // the direction the path arrived along
   double thr[3];
-  double u, v;        // hit record only
+  double u, v;
   uint64_t key;
   uint32_t path;
-  int32_t id;  // hit record only: >= 0 triangle slot, < 0 ~sphere index
+  int32_t id;  // >= 0 triangle slot, < 0 ~sphere index
   int32_t depth;
   int32_t pad;
 };
@@ -749,8 +747,8 @@ struct QueueView {
   uint32_t entries;   // entries per plane (segments * seg_cap)
   double* rad;        // [entries][3], only when the scene has emitters
   uint32_t seg_cap;   // records per segment
-  uint32_t hit_word;  // word of a counter line: hit records at the front of the segment
-  uint32_t ray_word;  // word of a counter line: ray records at the back of the segment
+  uint32_t hit_word;  // word of a counter line: records at the front of the segment (cheap rays)
+  uint32_t ray_word;  // word of a counter line: records at the back of the segment (long rays)
 };
 
 union QueueRecPieces {
@@ -786,13 +784,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
   int32_t* stk = g_stack + threadIdx.x;
   const int stride = blockDim.x;
   const int lane = threadIdx.x & 63;
-  const int unbounded = 0x7fffffff;
   WorkCount wc{};
   uint32_t n_done = 0;
   uint32_t seg;
   size_t entry = 0;
   bool alive;
-  bool ray_block = false;  // this block reads ray records (uniform over the block)
+  bool ray_block = false;  // this block reads the back run of its segment (uniform over the block)
   if (STAGE == 0) {
     seg = blockIdx.x % n_seg;
     alive = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x < pp.n_paths;
@@ -815,8 +812,6 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
   int depth = 0;
   d3 o = mk(0, 0, 0), dir = mk(0, 0, 0), thr = mk(1, 1, 1), rad = mk(0, 0, 0);
   uint32_t fuse_left = STAGE == 0 ? pp.fuse_bounces : 0u;
-  // node visits the next trace may make before its ray is queued instead
-  int budget = (STAGE == 1 && !ray_block) ? (int)pp.short_steps : unbounded;
 
   if (alive) {
     if (STAGE == 0) {
@@ -833,24 +828,20 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
       path = r->path;
       depth = r->depth;
       if (sc.has_emission) rad = mk(in.rad[entry * 3], in.rad[entry * 3 + 1], in.rad[entry * 3 + 2]);
-      if (ray_block) {
-        o = p0;
-      } else {
-        ShadeIn si;
-        si.hit_pos = p0;
-        si.u = r->u;
-        si.v = r->v;
-        const int32_t id = r->id;
-        si.slot = id >= 0 ? id : -1;
-        si.sphere = id >= 0 ? -1 : ~id;
-        if (COUNT) wc.shaded++;
-        shade_hit<COUNT>(sc, si, key, depth, o, dir, thr, rad, wc);
-        depth += 1;
-        if (depth > pp.max_depth) {  // src/main.rs:818
-          store_sample(samples, pp.n_paths, path, rad);
-          alive = false;
-          n_done++;
-        }
+      ShadeIn si;
+      si.hit_pos = p0;
+      si.u = r->u;
+      si.v = r->v;
+      const int32_t id = r->id;
+      si.slot = id >= 0 ? id : -1;
+      si.sphere = id >= 0 ? -1 : ~id;
+      if (COUNT) wc.shaded++;
+      shade_hit<COUNT>(sc, si, key, depth, o, dir, thr, rad, wc);
+      depth += 1;
+      if (depth > pp.max_depth) {  // src/main.rs:818
+        store_sample(samples, pp.n_paths, path, rad);
+        alive = false;
+        n_done++;
       }
     }
   }
@@ -858,35 +849,27 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
   HitK h;
   h.slot = -1;
   h.sphere = -1;
-  bool deferred = false;  // this lane's ray ran out of budget: queue the ray
+  int32_t steps = 0;  // node visits of the ray that found this lane's hit
   for (;;) {
     if (alive) {
       Trav t;
       trav_begin(t, sc, o, dir, stk);
-      if (budget == unbounded) trav_run<COUNT, false>(t, sc, stride, wc, 0);
-      else trav_run<COUNT, true>(t, sc, stride, wc, budget);
-      if (t.cur != RT_REF_SENTINEL) {
-        deferred = true;
+      trav_run<COUNT>(t, sc, stride, wc);
+      steps = t.steps;
+      wc.rays++;
+      finish_hit<COUNT>(sc, o, dir, t.best_t, t.best_u, t.best_v, t.best_slot, h, wc);
+      if (!(h.slot >= 0 || h.sphere >= 0)) {
+        const d3 s = sky(dir);  // src/main.rs:826
+        rad = rad + mk(thr.x * s.x, thr.y * s.y, thr.z * s.z);
+        store_sample(samples, pp.n_paths, path, rad);
         alive = false;
-      } else {
-        wc.rays++;  // a nearest-hit query is counted where it completes
-        finish_hit<COUNT>(sc, o, dir, t.best_t, t.best_u, t.best_v, t.best_slot, h, wc);
-        if (!(h.slot >= 0 || h.sphere >= 0)) {
-          const d3 s = sky(dir);  // src/main.rs:826
-          rad = rad + mk(thr.x * s.x, thr.y * s.y, thr.z * s.z);
-          store_sample(samples, pp.n_paths, path, rad);
-          alive = false;
-          n_done++;
-        }
+        n_done++;
       }
     }
     // from here on `alive` means: has a hit waiting to be shaded
     if (STAGE == 2 || (STAGE == 0 && fuse_left > 0)) {
       if (!__any(alive)) break;
-      if (STAGE == 0) {
-        fuse_left--;
-        budget = (int)pp.short_steps;
-      }
+      if (STAGE == 0) fuse_left--;
       if (alive) {
         if (COUNT) wc.shaded++;
         const ShadeIn si = shade_input(h, o, dir);
@@ -903,23 +886,24 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
     break;
   }
 
-  // append: hits at the front of this block's segment, unfinished rays at its back
+  // append: hits found by cheap rays at the front of this block's segment, the others at its back
   if (STAGE != 2) {
     unsigned long long* line = counters + (size_t)seg * RT_LINE_WORDS;
-    const unsigned long long hit_mask = __ballot(alive), ray_mask = __ballot(deferred);
+    const bool longer = alive && (uint32_t)steps >= pp.long_steps;
+    const unsigned long long hit_mask = __ballot(alive && !longer), ray_mask = __ballot(longer);
     size_t e = 0;
     if (hit_mask) {
       const uint32_t i = wave_reserve(&line[out.hit_word], hit_mask, lane);
-      if (alive) e = (size_t)seg * out.seg_cap + i;
+      if (alive && !longer) e = (size_t)seg * out.seg_cap + i;
     }
     if (ray_mask) {
       const uint32_t i = wave_reserve(&line[out.ray_word], ray_mask, lane);
-      if (deferred) e = (size_t)seg * out.seg_cap + (out.seg_cap - 1u - i);
+      if (longer) e = (size_t)seg * out.seg_cap + (out.seg_cap - 1u - i);
     }
-    if (alive || deferred) {
+    if (alive) {
       QueueRec rec_out;
       QueueRec* r = &rec_out;
-      const d3 p0 = alive ? o + h.t * dir : o;  // src/main.rs:831
+      const d3 p0 = o + h.t * dir;  // src/main.rs:831
       r->hit_pos[0] = p0.x;
       r->hit_pos[1] = p0.y;
       r->hit_pos[2] = p0.z;
@@ -929,13 +913,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
       r->thr[0] = thr.x;
       r->thr[1] = thr.y;
       r->thr[2] = thr.z;
-      r->u = alive ? h.u : 0.0;
-      r->v = alive ? h.v : 0.0;
+      r->u = h.u;
+      r->v = h.v;
       r->key = key;
       r->path = path;
-      r->id = alive ? (h.slot >= 0 ? h.slot : ~h.sphere) : 0;
+      r->id = h.slot >= 0 ? h.slot : ~h.sphere;
       r->depth = depth;
-      r->pad = 0;
+      r->pad = steps;
       queue_store(out, e, rec_out);
       if (sc.has_emission) {
         out.rad[e * 3] = rad.x;
@@ -947,7 +931,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
   flush_counts(wc, counters, COUNT, n_done);
 }
 
-// Copies the records still queued (hits at the front, rays at the back of every segment) into
+// Copies the records still queued (both runs of every segment: front and back) into
 // one compact segment, whose two counts live in line 0 of `out_counters`. The tail kernel then
 // runs from that copy on the side stream while the main stream reuses the queues.
 __global__ __launch_bounds__(RT_BLOCK) void k_gather(QueueView in, QueueView out, uint32_t hit_blocks, int has_rad,
@@ -1302,13 +1286,11 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
   const double divisor = (double)(p->spp_total ? p->spp_total : p->spp);
   const char* fuse_env = std::getenv("RT_FUSE_BOUNCES");
   const uint32_t fuse_bounces = fuse_env && *fuse_env ? (uint32_t)std::max(0, std::atoi(fuse_env)) : 1u;
-  // RT_SHORT_STEPS=n > 0 turns the long-ray queue on: a scattered ray that needs more than n node
-  // visits is queued and traced by a later launch. Off by default: measured on MI355X it cuts
-  // the VALU instructions of a frame by 11 % but the long-ray launches wait on memory, and the
-  // frame gets 3-5 % slower.
-  const char* short_env = std::getenv("RT_SHORT_STEPS");
-  uint32_t short_steps = short_env && *short_env ? (uint32_t)std::max(0, std::atoi(short_env)) : 0u;
-  if (short_steps == 0) short_steps = 0x7fffffffu;
+  // RT_LONG_STEPS=n: hits found after n or more node visits are queued apart from the others (0: all
+  // in one run).
+  const char* long_env = std::getenv("RT_LONG_STEPS");
+  uint32_t long_steps = long_env && *long_env ? (uint32_t)std::max(0, std::atoi(long_env)) : RT_LONG_STEPS_DEFAULT;
+  if (long_steps == 0) long_steps = 0x7fffffffu;
   int cus = 256;
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d->device);
   CounterSums now{};
@@ -1369,7 +1351,7 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
     pp.n_paths = (uint32_t)(n_pix * pp.spp);
     pp.max_depth = p->max_depth;
     pp.fuse_bounces = fuse_bounces;
-    pp.short_steps = short_steps;
+    pp.long_steps = long_steps;
     const uint32_t blocks_all = (pp.n_paths + RT_BLOCK - 1) / RT_BLOCK;
     // Every chunk but the last hands its tail and its resolve to the side stream; so does the
     // last chunk of a pipelined call.

@@ -182,9 +182,7 @@ __device__ __forceinline__ f2 mk2(float a, float b) {
 }
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
-// Per-lane traversal state, resumable: a lane can stop after a bounded number of steps and any
-// lane of the block can pick the ray up later (the stack lives in LDS and is addressed by the
-// column index of the lane that started the ray).
+// Per-lane traversal state (the stack lives in LDS, one column per lane).
 struct Trav {
   d3 o, d;
   float ix, iy, iz;                                 // reciprocal direction
@@ -194,6 +192,7 @@ struct Trav {
   int32_t best_slot, best_flat;
   int32_t cur;   // next node/leaf ref, RT_REF_SENTINEL when the traversal has finished
   int32_t* sp;   // top of the stack column (entries are `stride` ints apart)
+  int32_t steps; // interior nodes this ray has visited
 };
 
 // Culling ray: t = b * inv - (o -+ pad) * inv, one fused operation per plane (culling only; the
@@ -234,12 +233,12 @@ __device__ __forceinline__ void trav_begin(Trav& t, const SceneK& sc, const d3 o
   t.sp = stk;
   *t.sp = RT_REF_SENTINEL;
   t.cur = sc.root_ref;
+  t.steps = 0;
 }
 
-// Runs the traversal until it finishes (t.cur == RT_REF_SENTINEL) or, when BOUNDED, until the
-// lane has made `max_inner` node visits in this call.
-template <bool COUNT, bool BOUNDED>
-__device__ __forceinline__ void trav_run(Trav& t, const SceneK& sc, const int stride, WorkCount& wc, const int max_inner) {
+// Runs the traversal to its end (t.cur == RT_REF_SENTINEL).
+template <bool COUNT>
+__device__ __forceinline__ void trav_run(Trav& t, const SceneK& sc, const int stride, WorkCount& wc) {
   const double eps = 0.00000001;  // src/main.rs:185
   const d3 o = t.o, d = t.d;
   const float ix = t.ix, iy = t.iy, iz = t.iz;
@@ -252,13 +251,8 @@ __device__ __forceinline__ void trav_run(Trav& t, const SceneK& sc, const int st
   int steps = 0;
 
   while (cur != RT_REF_SENTINEL) {
-    bool paused = false;
     RT_ACC(wc, 5);
     while (cur >= 0) {
-      if (BOUNDED && steps >= max_inner) {
-        paused = true;
-        break;
-      }
       steps += 1;
       const float4* np = reinterpret_cast<const float4*>(sc.nodes + cur);
       const float4 bx = np[0], by = np[1], bz = np[2];
@@ -310,7 +304,7 @@ __device__ __forceinline__ void trav_run(Trav& t, const SceneK& sc, const int st
       }
     }
     RT_ACC(wc, 4);
-    if (paused || cur == RT_REF_SENTINEL) break;
+    if (cur == RT_REF_SENTINEL) break;
     // leaf
     const uint32_t leaf = (uint32_t)~cur;
     const uint32_t first = leaf >> RT_LEAF_BITS, cnt = (leaf & (uint32_t)(RT_LEAF_MAX - 1)) + 1u;
@@ -357,6 +351,7 @@ __device__ __forceinline__ void trav_run(Trav& t, const SceneK& sc, const int st
   t.best_flat = best_flat;
   t.cur = cur;
   t.sp = sp;
+  t.steps = steps;
 }
 
 // The sphere loop of Scene::hit, src/main.rs:802-810, on top of the nearest mesh hit.
@@ -399,7 +394,7 @@ __device__ __forceinline__ void trace_ray(const SceneK& sc, const d3 o, const d3
                                           HitK& h, WorkCount& wc) {
   Trav t;
   trav_begin(t, sc, o, d, stk);
-  trav_run<COUNT, false>(t, sc, stride, wc, 0);
+  trav_run<COUNT>(t, sc, stride, wc);
   finish_hit<COUNT>(sc, o, d, t.best_t, t.best_u, t.best_v, t.best_slot, h, wc);
 }
 

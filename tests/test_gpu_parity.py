@@ -211,9 +211,9 @@ def test_render_variants_are_bitwise_identical(gpu_scenes, monkeypatch):
     for env in ({"RT_WORK_BUFFER_MIB": "1"},          # several sample chunks
                 {"RT_TAIL_THRESHOLD": "1"},           # (almost) never switch to the looping tail kernel
                 {"RT_TAIL_THRESHOLD": "100000000"},   # tail kernel right after the first bounce
-                {"RT_SHORT_STEPS": "0"},              # no long-ray queue: every ray traced at once
-                {"RT_SHORT_STEPS": "1", "RT_TAIL_THRESHOLD": "1"},  # nearly every scattered ray queued as a long ray
-                {"RT_SHORT_STEPS": "8", "RT_FUSE_BOUNCES": "0"},    # first stage queues its primary hits
+                {"RT_LONG_STEPS": "0"},               # one run per segment: hits not filed by the cost of their ray
+                {"RT_LONG_STEPS": "1", "RT_TAIL_THRESHOLD": "1"},   # every hit in the back run
+                {"RT_LONG_STEPS": "6", "RT_FUSE_BOUNCES": "0"},     # first stage queues its primary hits, both runs in use
                 {"RT_FUSE_BOUNCES": "3", "RT_WORK_BUFFER_MIB": "1"},
                 {"RT_WORK_BUFFER_MIB": "1", "RT_NO_OVERLAP": "1"},  # chunks one after the other, no side stream
                 {"RT_WORK_BUFFER_MIB": "2", "RT_TAIL_THRESHOLD": "300"}):  # overlapped tails, queues that empty before the threshold

@@ -40,8 +40,8 @@ for k in range(cases):
     if rng.random() < 0.3:
         env["RT_FUSE_BOUNCES"] = str(int(rng.integers(0, 4)))
     if rng.random() < 0.2:
-        env["RT_SHORT_STEPS"] = str(int(rng.integers(1, 6)))
-    for key in ("RT_WORK_BUFFER_MIB", "RT_TAIL_THRESHOLD", "RT_FUSE_BOUNCES", "RT_SHORT_STEPS"):
+        env["RT_LONG_STEPS"] = str(int(rng.integers(1, 6)))
+    for key in ("RT_WORK_BUFFER_MIB", "RT_TAIL_THRESHOLD", "RT_FUSE_BOUNCES", "RT_LONG_STEPS"):
         os.environ.pop(key, None)
     os.environ.update(env)
     base = rng.random((h, w, 3))

@@ -26,7 +26,7 @@ CSRC = os.path.join(ROOT, "raytracer_amd", "csrc")
 PARTS = [
     ("rt_kernels.hip.h", "trav_run", r"while \(cur != RT_REF_SENTINEL\)", "trav_run: outer loop"),
     ("rt_kernels.hip.h", "trav_run", r"while \(cur >= 0\)", "trav_run: node step (inner loop)"),
-    ("rt_kernels.hip.h", "trav_run", r"if \(paused \|\| cur == RT_REF_SENTINEL\) break;", "trav_run: leaf loop (triangle test)"),
+    ("rt_kernels.hip.h", "trav_run", r"if \(cur == RT_REF_SENTINEL\) break;", "trav_run: leaf loop (triangle test)"),
     ("rt_kernels.hip.h", "trav_run", r"^\s*cur = \*sp;\s*$", "trav_run: pop after leaf"),
     ("rt_kernels.hip.h", "shade_hit", r"Rng rng;", "shade_hit: material set-up, normal map, texel"),
     ("rt_kernels.hip.h", "shade_hit", r"int phase = 0", "shade_hit: rejection loop"),

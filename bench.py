@@ -196,8 +196,10 @@ def main():
 
     def harvest():
         for l in scene.last_launches():
+            if l.kind == 1 and l.items == 0 and not l.folded:
+                continue  # a bounce launch queued beyond what the frame needed: nothing ran
             c = timed.setdefault(l.kind, [0.0, 0, 0])
-            c[0] += l.ms; c[1] += 1; c[2] += l.rays
+            c[0] += l.ms; c[1] += max(1, l.folded); c[2] += l.rays
 
     barrier()
     t0 = time.perf_counter()

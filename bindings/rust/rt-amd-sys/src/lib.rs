@@ -152,7 +152,7 @@ pub struct rt_launch_info {
     pub kind: u32,
     pub items: u32,
     pub ms: f32,
-    pub reserved: u32,
+    pub folded: u32,
     pub rays: u64,
     pub node_visits: u64,
     pub tri_tests: u64,

@@ -177,13 +177,17 @@ typedef struct rt_timing {
   uint32_t resolve_launches;
 } rt_timing;
 
-/* One kernel launch of the last render call, in launch order. */
+/* One kernel launch of the last render call, in launch order. Launches over the ray queue take
+ * their extent from counts kept on the device, so a call can queue more of them than the frame
+ * turns out to need; those show up with items = 0. */
 typedef struct rt_launch_info {
   uint32_t kind;        /* 0 first bounce (camera + trace), 1 bounce (shade + trace) over the ray
                            queue, 2 tail (loops to the end), 3 single-kernel form, 4 resolve     */
   uint32_t items;       /* paths / queue entries / pixels the launch started with               */
   float ms;             /* duration (RT_FLAG_TIMING), else 0                                    */
-  uint32_t reserved;
+  uint32_t folded;      /* 0: one launch. n > 0: the sums over n launches of this kind — a run of
+                           thousands of pipelined calls keeps its latest launches one by one and
+                           folds the older ones into one such entry per kind, at the front        */
   uint64_t rays;        /* nearest-hit queries the launch made                                   */
   uint64_t node_visits; /* RT_FLAG_COUNT_WORK                                                   */
   uint64_t tri_tests;   /* RT_FLAG_COUNT_WORK                                                   */

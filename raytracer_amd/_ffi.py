@@ -144,7 +144,7 @@ class rt_launch_info(C.Structure):
         ("kind", C.c_uint32),
         ("items", C.c_uint32),
         ("ms", C.c_float),
-        ("reserved", C.c_uint32),
+        ("folded", C.c_uint32),
         ("rays", C.c_uint64),
         ("node_visits", C.c_uint64),
         ("tri_tests", C.c_uint64),

@@ -47,6 +47,23 @@ using namespace rtk;
 enum { CNT_RAYS = 0, CNT_NODES, CNT_TRIS, CNT_SPHERES, CNT_SHADED, CNT_PATHS, CNT_Q0, CNT_R0, CNT_Q1, CNT_R1, CNT_WORK, CNT_WI_INNER, CNT_WI_LEAF, CNT_WI_REJECT, CNT_WAVES, CNT_N };
 #define RT_COUNTER_BYTES ((size_t)RT_SHARDS * RT_LINE_WORDS * sizeof(unsigned long long))
 
+// What k_plan (below) writes: the extent of the next launch over a queue, and a snapshot of the
+// cumulative work counters.
+struct alignas(16) PlanRec {
+  uint32_t hit_blocks, ray_blocks;  // blocks of RT_BLOCK records per segment: front run, back run
+  uint32_t n_hit, n_ray;            // records over all segments
+};
+struct LogRec {
+  unsigned long long w[CNT_N];  // sums of the counter lines when the snapshot was taken
+  uint32_t n_hit, n_ray;        // queue records counted by this plan
+  uint32_t overflow;            // some segment holds more records than it has room for (never, by construction)
+  uint32_t hit_blocks, ray_blocks;  // as in the plan
+  uint32_t pad;
+};
+#define RT_PLAN_RECS 4 /* PlanRec per plan slot: [0] the launch, [1] only if it fits `split_at`, [2] only if not */
+#define RT_PLAN_SLOTS 4096  /* ring of plans and counter snapshots; harvested long before it wraps */
+#define RT_LAUNCH_KEEP 4096 /* launch log entries kept one by one; older ones are folded per kind */
+
 struct DeviceScene {
   int device = -1;
   SceneK k{};
@@ -65,6 +82,28 @@ struct DeviceScene {
   unsigned long long* counters = nullptr;       // RT_SHARDS lines
   unsigned long long* cur_counters = nullptr;   // the lines the last call counted in (counters, or the static scratch's)
   unsigned long long* host_counters = nullptr;  // pinned mirror
+  // Launch extents decided on the device (k_plan) and the snapshots they leave behind.
+  PlanRec* plans = nullptr;      // device: RT_PLAN_SLOTS x RT_PLAN_RECS
+  LogRec* host_log = nullptr;    // pinned, written by the device: RT_PLAN_SLOTS snapshots
+  uint64_t snap_seq = 0;         // snapshots taken so far; slot = seq % RT_PLAN_SLOTS
+  uint64_t snap_floor = 0;       // snapshots below this one are no longer referenced
+  int64_t last_main_snap = -1;   // latest snapshot of the main / side stream's counters in this run
+  int64_t last_tail_snap = -1;
+  struct Account {               // a launch whose work is the difference of two snapshots
+    size_t log_index;
+    int64_t before, after;       // snapshot sequence numbers; before: -1 counters were zero, -2 base_main, -3 base_tail
+    int64_t items_from;          // >= 0: items = records counted by that snapshot's plan
+  };
+  std::vector<Account> accounts;
+  unsigned long long base_main[CNT_N] = {};  // the latest snapshots' sums, kept across a harvest (their slots may be reused)
+  unsigned long long base_tail[CNT_N] = {};
+  // How many bounce launches a frame of a given shape needed before its queue was down to the
+  // tail threshold: learnt on the first such frame (the host watches the counts), then reused, so
+  // that later frames are queued without the host waiting for anything.
+  uint64_t hist_key = 0;
+  uint32_t hist_rounds = 0;
+  std::vector<uint32_t> hist_blocks;  // record blocks per segment of bounce launch 0 .. hist_rounds - 1, then of the tail
+  bool hist_valid = false;
   // Overlapped tails: when a call runs in several sample chunks, the thin tail of long paths of
   // one chunk (and that chunk's resolve) runs on a side stream while the next chunk starts.
   hipStream_t side = nullptr;
@@ -76,21 +115,17 @@ struct DeviceScene {
   double* tail_rad[2] = {nullptr, nullptr};
   size_t tail_rad_bytes[2] = {0, 0};
   unsigned long long* tail_counters = nullptr;     // counter lines of the side stream's kernels
-  unsigned long long* host_snaps = nullptr;        // pinned: tail_counters after each overlapped tail
-  size_t host_snaps_lines = 0;                     // capacity, in snapshots
   bool side_used = false;                          // the last call ran kernels on the side stream
   // A run = one call, or consecutive RT_FLAG_PIPELINE calls, which share their accounting.
   bool run_open = false;                           // the last call was pipelined
   bool resolved_valid[2] = {false, false};         // ev_resolved[q] recorded since the side stream was last idle
   uint32_t chunk_seq = 0;                          // chunks started so far: parity of the double buffers
-  unsigned long long prev_w[CNT_N] = {};           // main counters at the last host read of this run
   struct Pending {                                 // a timed launch whose events have not been read yet
     size_t log_index;
     size_t ev0;
   };
   std::vector<Pending> pending;
   size_t n_events = 0;
-  std::vector<size_t> lump_entries;                // log entries of pipelined tails (no snapshot)
   // staging for the host-buffer entry points
   void* stage = nullptr;
   size_t stage_bytes = 0;
@@ -168,7 +203,8 @@ void rt_device_scene_free(DeviceScene* d) {
   if (d->totals) (void)hipFree(d->totals);
   if (d->counters) (void)hipFree(d->counters);
   if (d->tail_counters) (void)hipFree(d->tail_counters);
-  if (d->host_snaps) (void)hipHostFree(d->host_snaps);
+  if (d->plans) (void)hipFree(d->plans);
+  if (d->host_log) (void)hipHostFree(d->host_log);
   if (d->side) (void)hipStreamDestroy(d->side);
   for (int q = 0; q < 2; ++q)
     if (d->ev_join[q]) (void)hipEventDestroy(d->ev_join[q]);
@@ -286,6 +322,26 @@ int rt_device_scene_upload_from(const rt_scene* s, rt_scene* target, int device)
     unsigned char* sp = nullptr;
     if ((rc = scratch_address(device, &sp)) != RT_OK) return fail(rc);
   }
+  // everything a render call needs besides its work buffers exists from here on, so that the call
+  // itself creates nothing
+  if (hipMalloc((void**)&d->plans, (size_t)RT_PLAN_SLOTS * RT_PLAN_RECS * sizeof(PlanRec)) != hipSuccess ||
+      hipHostMalloc((void**)&d->host_log, (size_t)RT_PLAN_SLOTS * sizeof(LogRec), hipHostMallocDefault) != hipSuccess) {
+    rt_set_error("rt_scene_upload: allocation of the launch plans failed");
+    return fail(RT_ERR_HIP);
+  }
+  std::memset(d->host_log, 0, (size_t)RT_PLAN_SLOTS * sizeof(LogRec));
+  if (hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking) != hipSuccess) {
+    rt_set_error("rt_scene_upload: hipStreamCreate failed");
+    return fail(RT_ERR_HIP);
+  }
+  for (int q = 0; q < 2; ++q) {
+    if (hipEventCreateWithFlags(&d->ev_gathered[q], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&d->ev_resolved[q], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&d->ev_join[q], hipEventDisableTiming) != hipSuccess) {
+      rt_set_error("rt_scene_upload: hipEventCreate failed");
+      return fail(RT_ERR_HIP);
+    }
+  }
   if (hipHostMalloc((void**)&d->host_counters, RT_COUNTER_BYTES, hipHostMallocDefault) != hipSuccess) {
     rt_set_error("rt_scene_upload: hipHostMalloc of the counter mirror failed");
     return fail(RT_ERR_HIP);
@@ -371,33 +427,91 @@ static int harvest_timing(DeviceScene* d) {
   return RT_OK;
 }
 
-// Waits for everything the scene has queued on the caller's stream and on the side stream, then
-// completes the accounting of the run: launch durations, and the work of pipelined tails (whose
-// rays are known only in total and are reported on the last of them).
-static int finish_run(DeviceScene* d) {
+// Fills the launch log entries whose work is the difference of two counter snapshots (the caller
+// has waited for the streams the snapshots were taken on), then folds the oldest entries of a long
+// run into one entry per kind so that the log stays bounded.
+static int harvest_accounts(DeviceScene* d) {
+  bool overflow = false;
+  for (const DeviceScene::Account& a : d->accounts) {
+    const LogRec& after = d->host_log[(uint64_t)a.after % RT_PLAN_SLOTS];
+    unsigned long long zero[CNT_N] = {};
+    const unsigned long long* before = a.before >= 0 ? d->host_log[(uint64_t)a.before % RT_PLAN_SLOTS].w
+                                       : a.before == -2 ? d->base_main : a.before == -3 ? d->base_tail : zero;
+    rt_launch_info& li = d->launches[a.log_index];
+    li.rays = after.w[CNT_RAYS] - before[CNT_RAYS];
+    li.node_visits = after.w[CNT_NODES] - before[CNT_NODES];
+    li.tri_tests = after.w[CNT_TRIS] - before[CNT_TRIS];
+    li.waves = after.w[CNT_WAVES] - before[CNT_WAVES];
+    li.wave_iters_inner = after.w[CNT_WI_INNER] - before[CNT_WI_INNER];
+    li.wave_iters_leaf = after.w[CNT_WI_LEAF] - before[CNT_WI_LEAF];
+    li.wave_iters_reject = after.w[CNT_WI_REJECT] - before[CNT_WI_REJECT];
+    if (a.items_from >= 0) {
+      const LogRec& sized = d->host_log[(uint64_t)a.items_from % RT_PLAN_SLOTS];
+      li.items = sized.n_hit + sized.n_ray;
+    }
+    overflow = overflow || after.overflow != 0;
+  }
+  d->accounts.clear();
+  if (d->last_main_snap >= 0) {
+    std::memcpy(d->base_main, d->host_log[(uint64_t)d->last_main_snap % RT_PLAN_SLOTS].w, sizeof d->base_main);
+    d->last_main_snap = -2;
+  }
+  if (d->last_tail_snap >= 0) {
+    std::memcpy(d->base_tail, d->host_log[(uint64_t)d->last_tail_snap % RT_PLAN_SLOTS].w, sizeof d->base_tail);
+    d->last_tail_snap = -3;
+  }
+  d->snap_floor = d->snap_seq;
+  if (d->launches.size() > RT_LAUNCH_KEEP && d->pending.empty()) {
+    // entries [0, n_fold) become at most five entries (one per kind) in front of the rest
+    const size_t n_fold = d->launches.size() - RT_LAUNCH_KEEP / 2;
+    rt_launch_info folded[5];
+    std::memset(folded, 0, sizeof folded);
+    for (size_t i = 0; i < n_fold; ++i) {
+      const rt_launch_info& li = d->launches[i];
+      rt_launch_info& f = folded[li.kind < 5 ? li.kind : 4];
+      f.kind = li.kind;
+      f.ms += li.ms;
+      f.folded += li.folded ? li.folded : 1u;
+      f.items = (uint32_t)std::min<uint64_t>(0xffffffffull, (uint64_t)f.items + li.items);
+      f.rays += li.rays;
+      f.node_visits += li.node_visits;
+      f.tri_tests += li.tri_tests;
+      f.waves += li.waves;
+      f.wave_iters_inner += li.wave_iters_inner;
+      f.wave_iters_leaf += li.wave_iters_leaf;
+      f.wave_iters_reject += li.wave_iters_reject;
+    }
+    std::vector<rt_launch_info> kept;
+    for (const rt_launch_info& f : folded)
+      if (f.folded) kept.push_back(f);
+    kept.insert(kept.end(), d->launches.begin() + (long)n_fold, d->launches.end());
+    d->launches.swap(kept);
+  }
+  if (overflow) {
+    rt_set_error("internal error: a queue segment was handed more records than it has room for");
+    return RT_ERR_HIP;
+  }
+  return RT_OK;
+}
+
+// Waits for what the scene has queued on the caller's stream and on the side stream and fills in
+// the launch log (durations, work); does not end a run of pipelined calls.
+static int settle(DeviceScene* d) {
   HIP_TRY(hipSetDevice(d->device));
   if (d->last_stream_valid) HIP_TRY(hipStreamSynchronize(d->last_stream));
   if (d->side) HIP_TRY(hipStreamSynchronize(d->side));
   d->resolved_valid[0] = d->resolved_valid[1] = false;
   int rc = harvest_timing(d);
   if (rc != RT_OK) return rc;
-  if (!d->lump_entries.empty()) {
-    HIP_TRY(hipMemcpy(d->host_counters, d->tail_counters, RT_COUNTER_BYTES, hipMemcpyDeviceToHost));
-    CounterSums t;
-    std::memset(&t, 0, sizeof t);
-    sum_lines(d->host_counters, &t);
-    rt_launch_info& li = d->launches[d->lump_entries.back()];
-    li.rays = t.w[CNT_RAYS];
-    li.node_visits = t.w[CNT_NODES];
-    li.tri_tests = t.w[CNT_TRIS];
-    li.waves = t.w[CNT_WAVES];
-    li.wave_iters_inner = t.w[CNT_WI_INNER];
-    li.wave_iters_leaf = t.w[CNT_WI_LEAF];
-    li.wave_iters_reject = t.w[CNT_WI_REJECT];
-    d->lump_entries.clear();
-  }
+  d->n_events = 0;  // every event of the pool has been read: reuse them
+  return harvest_accounts(d);
+}
+
+// settle, and the run (one call, or consecutive RT_FLAG_PIPELINE calls) is over.
+static int finish_run(DeviceScene* d) {
+  int rc = settle(d);
   d->run_open = false;
-  return RT_OK;
+  return rc;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -443,7 +557,8 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
   return v;
 }
 
-__device__ __forceinline__ void flush_counts(const WorkCount& wc, unsigned long long* counters, bool count_all, uint32_t n_done) {
+__device__ __forceinline__ void flush_counts(const WorkCount& wc, unsigned long long* counters, bool count_all, uint32_t n_done,
+                                             uint32_t n_waves = 1) {
   // one atomic per wave and counter, on the wave's own line
   unsigned long long* line = my_line(counters);
   const unsigned long long r = wave_sum(wc.rays);
@@ -463,7 +578,7 @@ __device__ __forceinline__ void flush_counts(const WorkCount& wc, unsigned long 
       if (g) atomicAdd(&line[CNT_WI_INNER], g);
       if (h) atomicAdd(&line[CNT_WI_LEAF], h);
       if (i) atomicAdd(&line[CNT_WI_REJECT], i);
-      atomicAdd(&line[CNT_WAVES], 1ull);
+      if (n_waves) atomicAdd(&line[CNT_WAVES], (unsigned long long)n_waves);
     }
   }
 }
@@ -778,14 +893,116 @@ __device__ __forceinline__ uint32_t wave_reserve(unsigned long long* word, unsig
   return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
-template <bool COUNT, int STAGE>
+// How large the launches over a queue are is decided on the device: after every launch that
+// appends to a queue, one block (k_plan) adds up the segment counts and writes the extent of the
+// next launch — the blocks of 64 records the fullest segment holds in its front and back run —
+// for the kernels of that launch to read. Those kernels run on a fixed grid of (segments, some
+// blocks per segment) whose blocks loop over the record blocks of their segment, so the host
+// never has to know a count and a whole frame can be queued without waiting for any of it.
+// The same block leaves a snapshot of the cumulative work counters in host-visible memory, from
+// which the per-launch log is made once the frame is done.
+
+// One block of RT_SHARDS threads, thread t on counter line t. plan[0] = extent of the queue whose
+// counts are words in_hit_word / in_ray_word of the first n_seg lines; with split_at > 0 also
+// plan[1] = plan[0] if the queue holds at most split_at records, else empty, and plan[2] the other
+// way round. zero_word >= 0: words zero_word, zero_word + 1 of every line are set to zero (the
+// counts of the queue the next launch appends to). log (may be null) receives the snapshot.
+__global__ __launch_bounds__(RT_SHARDS) void k_plan(unsigned long long* counters, uint32_t in_hit_word, uint32_t in_ray_word, int zero_word,
+                                                    uint32_t n_seg, uint32_t seg_cap, uint32_t split_at, PlanRec* __restrict__ plan,
+                                                    LogRec* __restrict__ log) {
+  __shared__ unsigned long long s_sum[RT_SHARDS / 64][CNT_N + 2];
+  __shared__ uint32_t s_max[RT_SHARDS / 64][3];
+  const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63u;
+  unsigned long long* line = counters + (size_t)t * RT_LINE_WORDS;
+  uint32_t nh = 0, nr = 0;
+  if (t < n_seg) {
+    nh = (uint32_t)line[in_hit_word];
+    nr = (uint32_t)line[in_ray_word];
+  }
+  // sums of every word over the lines, and of the two counts over the segments: one word at a time
+#pragma unroll 1
+  for (int w = 0; w < CNT_N + 2; ++w) {
+    unsigned long long x = w < CNT_N ? line[w] : (w == CNT_N ? (unsigned long long)nh : (unsigned long long)nr);
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+    if (lane == 0) s_sum[wave][w] = x;
+  }
+  uint32_t mh = nh, mr = nr, ov = (uint64_t)nh + nr > seg_cap ? 1u : 0u;
+  for (int off = 32; off > 0; off >>= 1) {
+    mh = max(mh, (uint32_t)__shfl_down((int)mh, off));
+    mr = max(mr, (uint32_t)__shfl_down((int)mr, off));
+    ov |= (uint32_t)__shfl_down((int)ov, off);
+  }
+  if (lane == 0) {
+    s_max[wave][0] = mh;
+    s_max[wave][1] = mr;
+    s_max[wave][2] = ov;
+  }
+  __syncthreads();
+  if (zero_word >= 0) {
+    line[zero_word] = 0ull;
+    line[zero_word + 1] = 0ull;
+  }
+  if (t == 0) {
+    uint32_t max_h = 0, max_r = 0, over = 0;
+    for (int k = 0; k < RT_SHARDS / 64; ++k) {
+      max_h = max(max_h, s_max[k][0]);
+      max_r = max(max_r, s_max[k][1]);
+      over |= s_max[k][2];
+    }
+#pragma unroll 1
+    for (int w = 0; w < CNT_N + 2; ++w) {  // totals land in row 0
+      unsigned long long x = 0ull;
+      for (int k = 0; k < RT_SHARDS / 64; ++k) x += s_sum[k][w];
+      s_sum[0][w] = x;
+    }
+    const unsigned long long* tot = s_sum[0];
+    PlanRec pr;
+    pr.hit_blocks = (max_h + RT_BLOCK - 1) / RT_BLOCK;
+    pr.ray_blocks = (max_r + RT_BLOCK - 1) / RT_BLOCK;
+    pr.n_hit = (uint32_t)tot[CNT_N];
+    pr.n_ray = (uint32_t)tot[CNT_N + 1];
+    const PlanRec none{0u, 0u, 0u, 0u};
+    plan[0] = pr;
+    if (split_at > 0) {
+      const bool fits = (uint64_t)pr.n_hit + pr.n_ray <= split_at;
+      plan[1] = fits ? pr : none;
+      plan[2] = fits ? none : pr;
+    }
+    if (log) {
+      for (int w = 0; w < CNT_N; ++w) log->w[w] = tot[w];
+      log->n_hit = pr.n_hit;
+      log->n_ray = pr.n_ray;
+      log->overflow = over;
+      log->hit_blocks = pr.hit_blocks;
+      log->ray_blocks = pr.ray_blocks;
+      log->pad = 0;
+    }
+  }
+}
+
+// LOOP = false: workgroup (s, y) handles record block vb_base + y of segment s, or nothing if the
+// plan says the segment has fewer. LOOP = true: it handles blocks vb_base + y, + gridDim.y, ... to
+// the end — the form that cannot fall short whatever the counts turn out to be; it holds more
+// registers, so the host launches the first form on a grid sized from experience and the second
+// behind it for whatever that grid did not cover (normally nothing).
+template <bool COUNT, int STAGE, bool LOOP>
 __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, QueueView in, QueueView out, uint32_t n_seg,
-                                                   uint32_t hit_blocks, double* __restrict__ samples, unsigned long long* counters) {
+                                                   const PlanRec* __restrict__ plan, uint32_t vb_base, double* __restrict__ samples,
+                                                   unsigned long long* counters) {
   int32_t* stk = g_stack + threadIdx.x;
   const int stride = blockDim.x;
   const int lane = threadIdx.x & 63;
   WorkCount wc{};
-  uint32_t n_done = 0;
+  uint32_t n_done = 0, n_vb = 0;
+  // Stage 0: one block of paths per workgroup. Later stages: record blocks of the workgroup's
+  // segment, as many as the plan says there are.
+  uint32_t hit_blocks = 0, vb_end = 1;
+  if (STAGE != 0) {
+    hit_blocks = plan->hit_blocks;
+    vb_end = hit_blocks + plan->ray_blocks;
+  }
+  for (uint32_t vb = (STAGE != 0 ? vb_base : 0u) + blockIdx.y; vb < vb_end; vb += gridDim.y) {
+  n_vb++;
   uint32_t seg;
   size_t entry = 0;
   bool alive;
@@ -796,13 +1013,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
   } else {
     seg = blockIdx.x;
     const unsigned long long* line = counters + (size_t)seg * RT_LINE_WORDS;
-    ray_block = blockIdx.y >= hit_blocks;
+    ray_block = vb >= hit_blocks;
     if (!ray_block) {
-      const uint32_t i = blockIdx.y * RT_BLOCK + threadIdx.x;
+      const uint32_t i = vb * RT_BLOCK + threadIdx.x;
       alive = i < (uint32_t)line[in.hit_word];
       entry = (size_t)seg * in.seg_cap + i;
     } else {
-      const uint32_t i = (blockIdx.y - hit_blocks) * RT_BLOCK + threadIdx.x;
+      const uint32_t i = (vb - hit_blocks) * RT_BLOCK + threadIdx.x;
       alive = i < (uint32_t)line[in.ray_word];
       entry = (size_t)seg * in.seg_cap + (in.seg_cap - 1u - (alive ? i : 0u));
     }
@@ -928,39 +1145,46 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
       }
     }
   }
-  flush_counts(wc, counters, COUNT, n_done);
+  if (!LOOP) break;
+  }  // record blocks of this workgroup
+  flush_counts(wc, counters, COUNT, n_done, n_vb);
 }
 
 // Copies the records still queued (both runs of every segment: front and back) into
 // one compact segment, whose two counts live in line 0 of `out_counters`. The tail kernel then
 // runs from that copy on the side stream while the main stream reuses the queues.
-__global__ __launch_bounds__(RT_BLOCK) void k_gather(QueueView in, QueueView out, uint32_t hit_blocks, int has_rad,
+__global__ __launch_bounds__(RT_BLOCK) void k_gather(QueueView in, QueueView out, const PlanRec* __restrict__ plan, int has_rad,
                                                      const unsigned long long* __restrict__ in_counters, unsigned long long* out_counters) {
   const uint32_t seg = blockIdx.x;
   const int lane = threadIdx.x & 63;
   const unsigned long long* line = in_counters + (size_t)seg * RT_LINE_WORDS;
-  const bool ray_block = blockIdx.y >= hit_blocks;
-  bool alive;
-  size_t entry;
-  if (!ray_block) {
-    const uint32_t i = blockIdx.y * RT_BLOCK + threadIdx.x;
-    alive = i < (uint32_t)line[in.hit_word];
-    entry = (size_t)seg * in.seg_cap + i;
-  } else {
-    const uint32_t i = (blockIdx.y - hit_blocks) * RT_BLOCK + threadIdx.x;
-    alive = i < (uint32_t)line[in.ray_word];
-    entry = (size_t)seg * in.seg_cap + (in.seg_cap - 1u - (alive ? i : 0u));
-  }
-  const unsigned long long mask = __ballot(alive);
-  if (!mask) return;
-  const uint32_t i = wave_reserve(&out_counters[ray_block ? out.ray_word : out.hit_word], mask, lane);
-  if (!alive || i >= out.seg_cap) return;  // the host sized the segment for every record
-  const size_t e = ray_block ? (size_t)(out.seg_cap - 1u - i) : (size_t)i;
-  queue_store(out, e, queue_load(in, entry));
-  if (has_rad) {
-    out.rad[e * 3] = in.rad[entry * 3];
-    out.rad[e * 3 + 1] = in.rad[entry * 3 + 1];
-    out.rad[e * 3 + 2] = in.rad[entry * 3 + 2];
+  const uint32_t hit_blocks = plan->hit_blocks, vb_end = hit_blocks + plan->ray_blocks;
+  for (uint32_t vb = blockIdx.y; vb < vb_end; vb += gridDim.y) {
+    const bool ray_block = vb >= hit_blocks;
+    bool alive;
+    size_t entry;
+    if (!ray_block) {
+      const uint32_t i = vb * RT_BLOCK + threadIdx.x;
+      alive = i < (uint32_t)line[in.hit_word];
+      entry = (size_t)seg * in.seg_cap + i;
+    } else {
+      const uint32_t i = (vb - hit_blocks) * RT_BLOCK + threadIdx.x;
+      alive = i < (uint32_t)line[in.ray_word];
+      entry = (size_t)seg * in.seg_cap + (in.seg_cap - 1u - (alive ? i : 0u));
+    }
+    const unsigned long long mask = __ballot(alive);
+    if (!mask) continue;
+    const uint32_t i = wave_reserve(&out_counters[ray_block ? out.ray_word : out.hit_word], mask, lane);
+    // the plan this launch runs on is empty unless every record fits the segment; the two runs
+    // grow towards each other, so together they fit wherever they meet
+    if (!alive || i >= out.seg_cap) continue;
+    const size_t e = ray_block ? (size_t)(out.seg_cap - 1u - i) : (size_t)i;
+    queue_store(out, e, queue_load(in, entry));
+    if (has_rad) {
+      out.rad[e * 3] = in.rad[entry * 3];
+      out.rad[e * 3 + 1] = in.rad[entry * 3 + 1];
+      out.rad[e * 3 + 2] = in.rad[entry * 3 + 2];
+    }
   }
 }
 
@@ -1115,6 +1339,18 @@ static uint64_t queue_entries(uint32_t n_paths) {
   return (uint64_t)n_seg * ((blocks + n_seg - 1) / n_seg) * RT_BLOCK;
 }
 
+template <int STAGE>
+static void launch_wave(bool count, bool loop, dim3 grid, size_t lds, hipStream_t st, const SceneK& k, const PathParams& pp, const QueueView& in,
+                        const QueueView& out, uint32_t n_seg, const PlanRec* plan, uint32_t vb_base, double* samples, unsigned long long* counters) {
+  if (STAGE == 0 || !loop) {
+    if (count) hipLaunchKernelGGL((k_wave<true, STAGE, false>), grid, dim3(RT_BLOCK), lds, st, k, pp, in, out, n_seg, plan, vb_base, samples, counters);
+    else hipLaunchKernelGGL((k_wave<false, STAGE, false>), grid, dim3(RT_BLOCK), lds, st, k, pp, in, out, n_seg, plan, vb_base, samples, counters);
+  } else {
+    if (count) hipLaunchKernelGGL((k_wave<true, STAGE == 0 ? 1 : STAGE, true>), grid, dim3(RT_BLOCK), lds, st, k, pp, in, out, n_seg, plan, vb_base, samples, counters);
+    else hipLaunchKernelGGL((k_wave<false, STAGE == 0 ? 1 : STAGE, true>), grid, dim3(RT_BLOCK), lds, st, k, pp, in, out, n_seg, plan, vb_base, samples, counters);
+  }
+}
+
 // `arena` != nullptr: the call takes every work buffer out of the arena (the static work memory)
 // and makes no allocating call: no second sample buffer, no side stream, no events.
 static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas, float* d_sum, hipStream_t stream, const char* who,
@@ -1138,21 +1374,18 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
     // An earlier call may still have kernels queued on another stream; they read the counters and
     // work buffers this call is about to reset.
     if (d->last_stream_valid && d->last_stream != stream) {
-      if (arena) {
-        HIP_TRY(hipStreamSynchronize(d->last_stream));
-      } else {
-        if (!d->ev_join[0]) HIP_TRY(hipEventCreateWithFlags(&d->ev_join[0], hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(d->ev_join[0], d->last_stream));
-        HIP_TRY(hipStreamWaitEvent(stream, d->ev_join[0], 0));
-      }
+      HIP_TRY(hipEventRecord(d->ev_join[0], d->last_stream));
+      HIP_TRY(hipStreamWaitEvent(stream, d->ev_join[0], 0));
     }
     d->have_timing = false;
     d->launches.clear();
     d->pending.clear();
-    d->lump_entries.clear();
+    d->accounts.clear();
+    d->snap_floor = d->snap_seq;
+    d->last_main_snap = -1;
+    d->last_tail_snap = -1;
     d->n_events = 0;
     d->side_used = false;
-    std::memset(d->prev_w, 0, sizeof d->prev_w);
     std::memset(&d->timing, 0, sizeof d->timing);
     d->cur_counters = d->counters;
     if (arena) {
@@ -1258,26 +1491,14 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
     }
   }
   const uint32_t tail_threshold = (uint32_t)env_mib("RT_TAIL_THRESHOLD", 262144);
-  // one compact segment per parity holds a tail's input: a whole number of blocks of records
-  const uint32_t tail_cap = ((tail_threshold + RT_BLOCK - 1) / RT_BLOCK + 1) * RT_BLOCK;
+  // One compact segment per parity holds the input of a tail that runs on the side stream: room for
+  // twice the threshold (a frame queued from the learnt number of launches may arrive at the tail
+  // with somewhat more than the threshold), in whole blocks of records.
+  const uint32_t tail_cap = ((2u * tail_threshold + RT_BLOCK - 1) / RT_BLOCK + 1) * RT_BLOCK;
   if (overlap) {
-    if (!d->side) {
-      HIP_TRY(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
-      for (int q = 0; q < 2; ++q) {
-        HIP_TRY(hipEventCreateWithFlags(&d->ev_gathered[q], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&d->ev_resolved[q], hipEventDisableTiming));
-      }
-    }
     for (int q = 0; q < 2; ++q) {
       if ((rc = ensure_bytes(&d->tail_in[q], &d->tail_in_bytes[q], (size_t)tail_cap * sizeof(QueueRec))) != RT_OK) return rc;
       if (emission && (rc = ensure_bytes((void**)&d->tail_rad[q], &d->tail_rad_bytes[q], (size_t)tail_cap * 24u)) != RT_OK) return rc;
-    }
-    if (timing_or_count && !pipeline && d->host_snaps_lines < n_chunks) {
-      if (d->host_snaps) (void)hipHostFree(d->host_snaps);
-      d->host_snaps = nullptr;
-      d->host_snaps_lines = 0;
-      HIP_TRY(hipHostMalloc((void**)&d->host_snaps, (size_t)n_chunks * RT_COUNTER_BYTES, hipHostMallocDefault));
-      d->host_snaps_lines = n_chunks;
     }
     d->side_used = true;
   }
@@ -1291,9 +1512,13 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
   const char* long_env = std::getenv("RT_LONG_STEPS");
   uint32_t long_steps = long_env && *long_env ? (uint32_t)std::max(0, std::atoi(long_env)) : RT_LONG_STEPS_DEFAULT;
   if (long_steps == 0) long_steps = 0x7fffffffu;
+  // RT_GRID_BLOCKS: workgroups of a launch over a queue (they loop over the queue's record blocks)
+  const uint32_t grid_blocks = (uint32_t)env_mib("RT_GRID_BLOCKS", 32768);
+  // RT_SYNC_ROUNDS=1: the host watches the queue counts of every frame (as on a frame of a new shape)
+  const char* sync_env = std::getenv("RT_SYNC_ROUNDS");
+  const bool always_watch = sync_env && *sync_env && *sync_env != '0';
   int cus = 256;
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d->device);
-  CounterSums now{};
 
   // Launch log; with timing every launch is bracketed by two events of the pool.
   auto begin_launch = [&](uint32_t kind, uint32_t items, hipStream_t on) -> int {
@@ -1322,23 +1547,27 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
     }
     return RT_OK;
   };
-  auto account = [&](size_t log_index) {  // the main counters are cumulative over the run
-    rt_launch_info& li = d->launches[log_index];
-    li.rays = now.w[CNT_RAYS] - d->prev_w[CNT_RAYS];
-    li.node_visits = now.w[CNT_NODES] - d->prev_w[CNT_NODES];
-    li.tri_tests = now.w[CNT_TRIS] - d->prev_w[CNT_TRIS];
-    li.waves = now.w[CNT_WAVES] - d->prev_w[CNT_WAVES];
-    li.wave_iters_inner = now.w[CNT_WI_INNER] - d->prev_w[CNT_WI_INNER];
-    li.wave_iters_leaf = now.w[CNT_WI_LEAF] - d->prev_w[CNT_WI_LEAF];
-    li.wave_iters_reject = now.w[CNT_WI_REJECT] - d->prev_w[CNT_WI_REJECT];
-    std::memcpy(d->prev_w, now.w, sizeof d->prev_w);
+  // Queues a k_plan on `on` over the lines `lines`: the extent of the queue (in_hit_word,
+  // in_ray_word) for the next launch and a snapshot of the lines' sums. Returns the snapshot's
+  // sequence number in *seq; the plan records are at plan_at(seq).
+  auto plan_at = [&](int64_t seq) -> PlanRec* { return d->plans + ((uint64_t)seq % RT_PLAN_SLOTS) * RT_PLAN_RECS; };
+  auto take_plan = [&](hipStream_t on, unsigned long long* lines, uint32_t in_hit_word, uint32_t in_ray_word, int zero_word,
+                       uint32_t n_seg, uint32_t seg_cap, uint32_t split_at, int64_t* seq) -> int {
+    if (d->snap_seq - d->snap_floor >= RT_PLAN_SLOTS - 8) {  // the ring is about to wrap: settle what is in flight
+      int r = settle(d);
+      if (r != RT_OK) return r;
+    }
+    *seq = (int64_t)d->snap_seq++;
+    hipLaunchKernelGGL(k_plan, dim3(1), dim3(RT_SHARDS), 0, on, lines, in_hit_word, in_ray_word, zero_word, n_seg, seg_cap, split_at,
+                       plan_at(*seq), d->host_log + ((uint64_t)*seq % RT_PLAN_SLOTS));
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
   };
-
-  struct TailSnap {  // an overlapped tail: its log entry and its snapshot of the side counters
-    size_t log_index;
-    uint32_t snap;
+  // The work of the launch logged last = snapshot `after` minus the previous snapshot of the same lines.
+  auto account_main = [&](int64_t after, int64_t items_from) {
+    d->accounts.push_back(DeviceScene::Account{d->launches.size() - 1, d->last_main_snap, after, items_from});
+    d->last_main_snap = after;
   };
-  std::vector<TailSnap> tail_snaps;
 
   for (uint32_t c = 0; c < n_chunks; ++c) {
     PathParams pp;
@@ -1361,6 +1590,7 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
     // this parity's sample buffer and tail input were last read two chunks ago on the side stream
     if (overlap && d->resolved_valid[par]) HIP_TRY(hipStreamWaitEvent(stream, d->ev_resolved[par], 0));
     hipStream_t resolve_on = stream;
+    int64_t snap = -1;
 
     if (mega) {
       uint32_t grid = blocks_all;
@@ -1377,89 +1607,137 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
         else hipLaunchKernelGGL((k_paths<false, false>), dim3(grid), dim3(RT_BLOCK), lds, stream, d->k, pp, samples, counters);
       }
       if ((rc = end_launch(stream)) != RT_OK) return rc;
+      if ((rc = take_plan(stream, counters, CNT_Q0, CNT_R0, -1, 0u, 0u, 0u, &snap)) != RT_OK) return rc;
+      account_main(snap, -1);
     } else {
-      // wavefront: stage 0 over all paths, then launches over the queued hits and long rays
+      // wavefront: stage 0 over all paths, then launches over the queued hits
       const uint32_t n_seg = choose_segments(pp.n_paths);
       const uint32_t seg_cap = ((blocks_all + n_seg - 1) / n_seg) * RT_BLOCK;
       QueueView qv[2];
       for (int q = 0; q < 2; ++q)
         qv[q] = QueueView{(float4*)queue[q], n_seg * seg_cap, queue_rad[q], seg_cap, (uint32_t)(q ? CNT_Q1 : CNT_Q0), (uint32_t)(q ? CNT_R1 : CNT_R0)};
       const size_t line_bytes = RT_LINE_WORDS * sizeof(unsigned long long);
+      // grid of the looping form of the launches over a queue (it covers whatever the sized grid of
+      // the plain form did not): a few workgroups per segment
+      const uint32_t seg_blocks = seg_cap / RT_BLOCK;
+      const dim3 qgrid(n_seg, std::max<uint32_t>(1u, std::min<uint32_t>(seg_blocks, (grid_blocks + n_seg - 1) / n_seg)));
       // the four counts of every line start at zero (adjacent words)
       HIP_TRY(hipMemset2DAsync(counters + CNT_Q0, line_bytes, 0, 4 * sizeof(unsigned long long), RT_SHARDS, stream));
       if ((rc = begin_launch(0, pp.n_paths, stream)) != RT_OK) return rc;
-      if (count) hipLaunchKernelGGL((k_wave<true, 0>), dim3(blocks_all), dim3(RT_BLOCK), lds, stream, d->k, pp, qv[0], qv[0], n_seg, 0u, samples, counters);
-      else hipLaunchKernelGGL((k_wave<false, 0>), dim3(blocks_all), dim3(RT_BLOCK), lds, stream, d->k, pp, qv[0], qv[0], n_seg, 0u, samples, counters);
+      launch_wave<0>(count, false, dim3(blocks_all), lds, stream, d->k, pp, qv[0], qv[0], n_seg, nullptr, 0u, samples, counters);
       if ((rc = end_launch(stream)) != RT_OK) return rc;
+      // the split of the plan (gather into the tail segment, or tail in place) only matters to the
+      // launches after the last bounce, and costs nothing on the others
+      const uint32_t split_at = handoff ? tail_cap : 0u;
+      if ((rc = take_plan(stream, counters, CNT_Q0, CNT_R0, CNT_Q1, n_seg, seg_cap, split_at, &snap)) != RT_OK) return rc;
+      account_main(snap, -1);
+
+      // Bounce launches. A frame of a shape seen before is queued blind, with as many launches as
+      // that frame needed; on a new shape the host waits for each plan and stops at the threshold.
+      uint64_t key = 0xcbf29ce484222325ull;
+      for (uint64_t v : {(uint64_t)pp.n_paths, (uint64_t)pp.spp, (uint64_t)p->width, (uint64_t)p->height, (uint64_t)(uint32_t)p->max_depth,
+                         (uint64_t)p->tile_size, (uint64_t)p->tile_rank, (uint64_t)p->tile_ranks, (uint64_t)fuse_bounces, (uint64_t)long_steps,
+                         (uint64_t)tail_threshold, (uint64_t)(p->flags & RT_FLAG_NO_JITTER)})
+        key = (key ^ v) * 0x100000001b3ull;
+      const bool learnt = !always_watch && d->hist_valid && d->hist_key == key;
+      std::vector<uint32_t> seen;  // record blocks per segment, launch by launch (a frame of a new shape)
+      // Grid of the plain form of launch `r` over a queue: exactly what the plan says when the host
+      // has read it, else what the frame this shape was learnt on needed plus an eighth; the
+      // looping form behind it covers the rest, if there is any.
+      auto sized_grid = [&](uint32_t r, int64_t plan_seq, uint32_t* gy) -> bool {
+        if (!learnt) {
+          const LogRec& lr = d->host_log[(uint64_t)plan_seq % RT_PLAN_SLOTS];
+          *gy = lr.hit_blocks + lr.ray_blocks;
+          seen.push_back(*gy);
+          return false;  // exact: nothing left to cover
+        }
+        const uint32_t h = r < d->hist_blocks.size() ? d->hist_blocks[r] : 0u;
+        *gy = std::min<uint32_t>(seg_blocks, h + h / 8u + 2u);
+        return *gy < seg_blocks;
+      };
+      uint32_t rounds = 0;
       int cur = 0;
       for (;;) {
-        if ((rc = read_counters(d, stream, &now)) != RT_OK) return rc;
-        account(d->launches.size() - 1);
-        const int hit_word = cur ? CNT_Q1 : CNT_Q0, ray_word = cur ? CNT_R1 : CNT_R0;
-        const uint64_t n_in = now.w[hit_word] + now.w[ray_word];
-        if (n_in == 0) break;
-        uint32_t max_hit = 0, max_ray = 0;
-        bool overflow = false;
-        for (uint32_t sgi = 0; sgi < n_seg; ++sgi) {
-          const uint64_t nh = d->host_counters[(size_t)sgi * RT_LINE_WORDS + hit_word];
-          const uint64_t nr = d->host_counters[(size_t)sgi * RT_LINE_WORDS + ray_word];
-          overflow = overflow || nh + nr > seg_cap;
-          max_hit = std::max<uint32_t>(max_hit, (uint32_t)nh);
-          max_ray = std::max<uint32_t>(max_ray, (uint32_t)nr);
+        if (learnt) {
+          if (rounds >= d->hist_rounds) break;
+        } else {
+          HIP_TRY(hipStreamSynchronize(stream));
+          const LogRec& lr = d->host_log[(uint64_t)snap % RT_PLAN_SLOTS];
+          if (lr.overflow || (uint64_t)lr.n_hit + lr.n_ray > pp.n_paths) {
+            rt_set_error("%s: internal error: a queue segment holds more than its %u records", who, seg_cap);
+            return RT_ERR_HIP;
+          }
+          if ((uint64_t)lr.n_hit + lr.n_ray <= tail_threshold) break;
         }
-        if (overflow || n_in > pp.n_paths) {
-          rt_set_error("%s: internal error: a queue segment holds more than its %u records", who, seg_cap);
-          return RT_ERR_HIP;
-        }
-        const uint32_t hit_blocks = (max_hit + RT_BLOCK - 1) / RT_BLOCK, ray_blocks = (max_ray + RT_BLOCK - 1) / RT_BLOCK;
-        const dim3 grid(n_seg, hit_blocks + ray_blocks);
         const int nxt = cur ^ 1;
-        if (n_in <= tail_threshold && handoff) {
-          // compact what is left into this parity's tail segment; the side stream takes it from there
-          const QueueView tv{(float4*)d->tail_in[par], tail_cap, d->tail_rad[par], tail_cap, (uint32_t)(par ? CNT_Q1 : CNT_Q0), (uint32_t)(par ? CNT_R1 : CNT_R0)};
-          HIP_TRY(hipMemsetAsync(d->tail_counters + tv.hit_word, 0, 2 * sizeof(unsigned long long), stream));
-          hipLaunchKernelGGL(k_gather, grid, dim3(RT_BLOCK), 0, stream, qv[cur], tv, hit_blocks, (int)emission, counters, d->tail_counters);
-          HIP_TRY(hipGetLastError());
-          HIP_TRY(hipEventRecord(d->ev_gathered[par], stream));
-          HIP_TRY(hipStreamWaitEvent(d->side, d->ev_gathered[par], 0));
-          const uint32_t thb = (uint32_t)((now.w[hit_word] + RT_BLOCK - 1) / RT_BLOCK), trb = (uint32_t)((now.w[ray_word] + RT_BLOCK - 1) / RT_BLOCK);
-          if ((rc = begin_launch(2, (uint32_t)n_in, d->side)) != RT_OK) return rc;
-          if (count) hipLaunchKernelGGL((k_wave<true, 2>), dim3(1, thb + trb), dim3(RT_BLOCK), lds, d->side, d->k, pp, tv, tv, 1u, thb, samples, d->tail_counters);
-          else hipLaunchKernelGGL((k_wave<false, 2>), dim3(1, thb + trb), dim3(RT_BLOCK), lds, d->side, d->k, pp, tv, tv, 1u, thb, samples, d->tail_counters);
-          if ((rc = end_launch(d->side)) != RT_OK) return rc;
-          if (pipeline) {
-            d->lump_entries.push_back(d->launches.size() - 1);
-          } else if (timing_or_count) {
-            const uint32_t snap = (uint32_t)tail_snaps.size();
-            HIP_TRY(hipMemcpyAsync(d->host_snaps + (size_t)snap * RT_SHARDS * RT_LINE_WORDS, d->tail_counters, RT_COUNTER_BYTES, hipMemcpyDeviceToHost, d->side));
-            tail_snaps.push_back(TailSnap{d->launches.size() - 1, snap});
-          }
-          resolve_on = d->side;
-          break;
-        }
-        if (n_in <= tail_threshold) {
-          if ((rc = begin_launch(2, (uint32_t)n_in, stream)) != RT_OK) return rc;
-          if (count) hipLaunchKernelGGL((k_wave<true, 2>), grid, dim3(RT_BLOCK), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, hit_blocks, samples, counters);
-          else hipLaunchKernelGGL((k_wave<false, 2>), grid, dim3(RT_BLOCK), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, hit_blocks, samples, counters);
-          if ((rc = end_launch(stream)) != RT_OK) return rc;
-          if (count || timing) {
-            if ((rc = read_counters(d, stream, &now)) != RT_OK) return rc;
-            account(d->launches.size() - 1);
-          }
-          break;
-        }
-        HIP_TRY(hipMemset2DAsync(counters + (nxt ? CNT_Q1 : CNT_Q0), line_bytes, 0, 2 * sizeof(unsigned long long), RT_SHARDS, stream));
-        if ((rc = begin_launch(1, (uint32_t)n_in, stream)) != RT_OK) return rc;
-        if (count) hipLaunchKernelGGL((k_wave<true, 1>), grid, dim3(RT_BLOCK), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, hit_blocks, samples, counters);
-        else hipLaunchKernelGGL((k_wave<false, 1>), grid, dim3(RT_BLOCK), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, hit_blocks, samples, counters);
+        uint32_t gy = 0;
+        const bool cover = sized_grid(rounds, snap, &gy);
+        if ((rc = begin_launch(1, 0u, stream)) != RT_OK) return rc;
+        if (gy) launch_wave<1>(count, false, dim3(n_seg, gy), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, plan_at(snap), 0u, samples, counters);
+        if (cover) launch_wave<1>(count, true, qgrid, lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, plan_at(snap), gy, samples, counters);
         if ((rc = end_launch(stream)) != RT_OK) return rc;
+        const int64_t sized_by = snap;
+        // counts of the queue just written; the counts of the one just read start the next round at zero
+        if ((rc = take_plan(stream, counters, qv[nxt].hit_word, qv[nxt].ray_word, (int)qv[cur].hit_word, n_seg, seg_cap, split_at, &snap)) != RT_OK) return rc;
+        account_main(snap, sized_by);
         cur = nxt;
+        rounds++;
+      }
+      const int nxt = cur ^ 1;
+
+      // What is left loops to its end in the tail kernel.
+      if (handoff) {
+        // If it fits the tail segment (plan record 1 is then the extent, record 2 empty) it is
+        // compacted into it and the side stream takes it from there, next to the next chunk or
+        // frame; otherwise (record 1 empty, record 2 the extent) the tail runs here, in place.
+        const QueueView tv{(float4*)d->tail_in[par], tail_cap, d->tail_rad[par], tail_cap, (uint32_t)(par ? CNT_Q1 : CNT_Q0), (uint32_t)(par ? CNT_R1 : CNT_R0)};
+        HIP_TRY(hipMemsetAsync(d->tail_counters + tv.hit_word, 0, 2 * sizeof(unsigned long long), stream));
+        hipLaunchKernelGGL(k_gather, qgrid, dim3(RT_BLOCK), 0, stream, qv[cur], tv, (const PlanRec*)(plan_at(snap) + 1), (int)emission, counters, d->tail_counters);
+        HIP_TRY(hipGetLastError());
+        if ((rc = begin_launch(2, 0u, stream)) != RT_OK) return rc;
+        launch_wave<2>(count, true, qgrid, lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, plan_at(snap) + 2, 0u, samples, counters);
+        if ((rc = end_launch(stream)) != RT_OK) return rc;
+        {
+          int64_t after;
+          if ((rc = take_plan(stream, counters, CNT_Q0, CNT_R0, -1, 0u, 0u, 0u, &after)) != RT_OK) return rc;
+          account_main(after, -1);
+        }
+        HIP_TRY(hipEventRecord(d->ev_gathered[par], stream));
+        HIP_TRY(hipStreamWaitEvent(d->side, d->ev_gathered[par], 0));
+        // on the side stream: extent of the compact segment (and the side counters before the tail), the tail, the counters after
+        int64_t tplan, tafter;
+        if ((rc = take_plan(d->side, d->tail_counters, tv.hit_word, tv.ray_word, -1, 1u, tail_cap, 0u, &tplan)) != RT_OK) return rc;
+        if ((rc = begin_launch(2, 0u, d->side)) != RT_OK) return rc;
+        launch_wave<2>(count, false, dim3(1, tail_cap / RT_BLOCK), lds, d->side, d->k, pp, tv, tv, 1u, plan_at(tplan), 0u, samples, d->tail_counters);
+        if ((rc = end_launch(d->side)) != RT_OK) return rc;
+        if ((rc = take_plan(d->side, d->tail_counters, tv.hit_word, tv.ray_word, -1, 0u, 0u, 0u, &tafter)) != RT_OK) return rc;
+        d->accounts.push_back(DeviceScene::Account{d->launches.size() - 1, tplan, tafter, tplan});
+        d->last_tail_snap = tafter;
+        resolve_on = d->side;
+        if (!learnt) seen.push_back(0u);
+      } else {
+        if (!learnt) HIP_TRY(hipStreamSynchronize(stream));  // the last plan may not have been read yet
+        uint32_t gy = 0;
+        const bool cover = sized_grid(rounds, snap, &gy);
+        if ((rc = begin_launch(2, 0u, stream)) != RT_OK) return rc;
+        if (gy) launch_wave<2>(count, false, dim3(n_seg, gy), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, plan_at(snap), 0u, samples, counters);
+        if (cover) launch_wave<2>(count, true, qgrid, lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, plan_at(snap), gy, samples, counters);
+        if ((rc = end_launch(stream)) != RT_OK) return rc;
+        const int64_t sized_by = snap;
+        if ((rc = take_plan(stream, counters, CNT_Q0, CNT_R0, -1, 0u, 0u, 0u, &snap)) != RT_OK) return rc;
+        account_main(snap, sized_by);
+      }
+      if (!learnt) {
+        d->hist_key = key;
+        d->hist_rounds = rounds;
+        d->hist_blocks.swap(seen);
+        d->hist_valid = true;
       }
     }
     // The running per-pixel totals pass from chunk to chunk in order: a handed-off chunk resolves
     // on the side stream (after its tail); the last chunk resolves on the caller's stream after
     // everything the side stream still holds.
-    if (handoff && resolve_on == stream) {  // the queue ran empty before the tail threshold
+    if (handoff && resolve_on == stream) {  // single-kernel form: nothing was handed over
       HIP_TRY(hipEventRecord(d->ev_gathered[par], stream));
       HIP_TRY(hipStreamWaitEvent(d->side, d->ev_gathered[par], 0));
       resolve_on = d->side;
@@ -1474,27 +1752,6 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
       HIP_TRY(hipEventRecord(d->ev_resolved[par], d->side));
       d->resolved_valid[par] = true;
     }
-  }
-  if (!tail_snaps.empty()) {  // per-launch work of the overlapped tails, from their snapshots
-    HIP_TRY(hipStreamSynchronize(d->side));
-    CounterSums before{};
-    for (const TailSnap& ts : tail_snaps) {
-      CounterSums after{};
-      sum_lines(d->host_snaps + (size_t)ts.snap * RT_SHARDS * RT_LINE_WORDS, &after);
-      rt_launch_info& li = d->launches[ts.log_index];
-      li.rays = after.w[CNT_RAYS] - before.w[CNT_RAYS];
-      li.node_visits = after.w[CNT_NODES] - before.w[CNT_NODES];
-      li.tri_tests = after.w[CNT_TRIS] - before.w[CNT_TRIS];
-      li.waves = after.w[CNT_WAVES] - before.w[CNT_WAVES];
-      li.wave_iters_inner = after.w[CNT_WI_INNER] - before.w[CNT_WI_INNER];
-      li.wave_iters_leaf = after.w[CNT_WI_LEAF] - before.w[CNT_WI_LEAF];
-      li.wave_iters_reject = after.w[CNT_WI_REJECT] - before.w[CNT_WI_REJECT];
-      before = after;
-    }
-  }
-  if (timing && !pipeline) {
-    HIP_TRY(hipStreamSynchronize(stream));
-    if ((rc = harvest_timing(d)) != RT_OK) return rc;
   }
   return RT_OK;
 }

@@ -225,5 +225,6 @@ extern "C" {
     pub fn rt_scene_last_timing(scene: *mut rt_scene, out: *mut rt_timing) -> c_int;
     pub fn rt_scene_last_launches(scene: *mut rt_scene, out: *mut rt_launch_info, capacity: u32, n_out: *mut u32) -> c_int;
     pub fn rt_quantize_rgba8(canvas: *const f64, width: u32, height: u32, its: u32, out: *mut u8) -> c_int;
+    pub fn rt_selftest_division(n: u64, seed: u64, mismatches: *mut u64) -> c_int;
     pub fn rt_last_error() -> *const c_char;
 }

@@ -405,6 +405,13 @@ int rt_group_member_info(const rt_group* group, uint32_t member, int* device, ui
  * does at src/main.rs:1106-1112. Host buffers; out is [height][width][4]. */
 int rt_quantize_rgba8(const double* canvas, uint32_t width, uint32_t height, uint32_t its, uint8_t* out);
 
+/* No counterpart in the reference. The kernels divide a vector by its length (normalize,
+ * src/main.rs:87-90) and colour bytes by 255 (src/main.rs:359, 404-406) with one refined
+ * reciprocal per denominator instead of three full divisions; this runs n pseudo-random and
+ * boundary operand triples through both forms on device 0 and counts the triples whose quotients
+ * differ in any bit from the plain IEEE divisions (expected: 0). */
+int rt_selftest_division(uint64_t n, uint64_t seed, uint64_t* mismatches);
+
 const char* rt_last_error(void);
 
 #ifdef __cplusplus

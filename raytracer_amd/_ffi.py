@@ -209,6 +209,7 @@ SIGNATURES = {
     "rt_scene_last_timing": (C.c_int, [_P, C.POINTER(rt_timing)]),
     "rt_scene_last_launches": (C.c_int, [_P, C.POINTER(rt_launch_info), C.c_uint32, C.POINTER(C.c_uint32)]),
     "rt_quantize_rgba8": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32, _P]),
+    "rt_selftest_division": (C.c_int, [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     "rt_last_error": (C.c_char_p, []),
 }
 

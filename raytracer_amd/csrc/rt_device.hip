@@ -681,7 +681,7 @@ __host__ __device__ inline bool tile_pixel(const TileMap& tm, uint32_t tile, uin
 struct PathParams {
   CameraK cam;
   TileMap tm;
-  uint64_t seed;
+  uint64_t seed_key;      // rtk::seed_key(seed)
   uint32_t n_paths;       // n_tiles * spp * 64, < 2^32 per launch
   uint32_t spp;           // samples in this launch
   FastDiv d_spp;
@@ -700,7 +700,7 @@ __device__ __forceinline__ bool start_path(const PathParams& pp, uint32_t g, uin
   const uint32_t s = g - tile * pp.spp;
   uint32_t x, y;
   if (!tile_pixel(pp.tm, tile, path & 63u, &x, &y)) return false;
-  key = path_key(pp.seed, (uint64_t)y * pp.tm.width + x, (uint64_t)pp.first_sample + s);
+  key = path_key(pp.seed_key, (uint64_t)y * pp.tm.width + x, (uint64_t)pp.first_sample + s);
   camera_ray(pp.cam, x, y, key, o, dir);
   return true;
 }
@@ -1573,7 +1573,7 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
     PathParams pp;
     pp.cam = make_camera(p);
     pp.tm = tm;
-    pp.seed = p->seed;
+    pp.seed_key = seed_key(p->seed);
     pp.spp = std::min(chunk, p->spp - c * chunk);
     pp.d_spp = make_fastdiv(pp.spp);
     pp.first_sample = p->first_sample + c * chunk;
@@ -1910,6 +1910,82 @@ static int rt_primary_hits_body(rt_scene* s, const rt_render_params* p, int32_t*
   d->last_stream_valid = true;
   d->side_used = false;
   return RT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Arithmetic self-test: the kernels divide a vector by its length, and colour bytes by 255, with
+// one refined reciprocal per denominator (rtk::div3_by_length, rtk::div3_in_range); this checks on
+// the device that the quotients are the bits of the plain IEEE divisions, on pseudo-random and on
+// boundary operands.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool same_bits(double a, double b) {
+  return __double_as_longlong(a) == __double_as_longlong(b) || (a != a && b != b);
+}
+__global__ __launch_bounds__(256) void k_selftest_div(uint64_t n, uint64_t seed, unsigned long long* mismatches) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long bad = 0;
+  uint64_t z[3];
+  for (int k = 0; k < 3; ++k) z[k] = mix64(seed + RT_GOLDEN * (3 * i + k + 1));
+  const uint32_t mode = (uint32_t)(mix64(seed ^ (i * 0x9e3779b97f4a7c15ull + 7)) & 15u);
+  d3 a;
+  double* comp[3] = {&a.x, &a.y, &a.z};
+  for (int k = 0; k < 3; ++k) {
+    uint64_t bits = z[k];
+    const uint64_t mant = bits & 0xfffffffffffffull, sign = bits & 0x8000000000000000ull;
+    uint64_t ex = (bits >> 52) & 0x7ffull;
+    if (mode < 8) ex = 1023 - 40 + (ex % 80);                     // moderate magnitudes: the rendering case
+    else if (mode == 8) ex = 1023 - 1000 + (ex % 2000);           // nearly the whole range
+    else if (mode == 9) ex = (ex % 3 == 0) ? 0 : 1023 - 8 + ex % 16;  // a denormal or zero-exponent component among ordinary ones
+    else if (mode == 10) ex = 1023 - 420 + (ex % 40);             // lengths around the lower edge of the fast range
+    else if (mode == 11) ex = 1023 + 380 + (ex % 40);             // and around the upper edge
+    else if (mode == 12) ex = (k == (int)(bits % 3)) ? 1023 - 950 + (ex % 100) : 1023 + (ex % 4);  // one tiny numerator
+    // modes 13..15: raw bits (NaNs, infinities, denormals as they come)
+    bits = sign | (ex << 52) | mant;
+    if (mode == 13 && (bits & 0xf00) == 0) bits = sign;            // some exact zeros of either sign
+    if (mode < 8 && (z[(k + 1) % 3] & 0x3f) == 0) bits = sign;     // axis-aligned vectors
+    *comp[k] = __longlong_as_double((long long)bits);
+  }
+  const double l = length(a);
+  const d3 fast = div3_by_length(a, l);
+  if (!same_bits(fast.x, a.x / l) || !same_bits(fast.y, a.y / l) || !same_bits(fast.z, a.z / l)) bad++;
+  const d3 px = mk((double)(z[0] & 255u), (double)(z[1] & 255u), (double)(z[2] & 255u));
+  const d3 c = div3_in_range(px, 255.0);
+  if (!same_bits(c.x, px.x / 255.0) || !same_bits(c.y, px.y / 255.0) || !same_bits(c.z, px.z / 255.0)) bad++;
+  const unsigned long long total = wave_sum(bad);
+  if ((threadIdx.x & 63) == 0 && total) atomicAdd(mismatches, total);
+}
+
+extern "C" int rt_selftest_division(uint64_t n, uint64_t seed, uint64_t* mismatches) {
+  return rt_guard("rt_selftest_division", [&] {
+    if (!mismatches) {
+      rt_set_error("rt_selftest_division: null argument");
+      return RT_ERR_INVALID;
+    }
+    if (rt_device_count() <= 0) {
+      rt_set_error("rt_selftest_division: no HIP device is visible");
+      return RT_ERR_NO_DEVICE;
+    }
+    unsigned long long* d_bad = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_bad, sizeof(unsigned long long)));
+    int rc = RT_OK;
+    auto body = [&]() -> int {
+      HIP_TRY(hipMemset(d_bad, 0, sizeof(unsigned long long)));
+      const uint64_t per_launch = 1ull << 28;
+      for (uint64_t done = 0; done < n; done += per_launch) {
+        const uint64_t m = std::min<uint64_t>(per_launch, n - done);
+        hipLaunchKernelGGL(k_selftest_div, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, nullptr, m, seed + done, d_bad);
+        HIP_TRY(hipGetLastError());
+      }
+      unsigned long long bad = 0;
+      HIP_TRY(hipMemcpy(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost));
+      *mismatches = bad;
+      return RT_OK;
+    };
+    rc = body();
+    (void)hipFree(d_bad);
+    return rc;
+  });
 }
 
 static int rt_scene_wait_body(rt_scene* s);

@@ -40,10 +40,47 @@ __device__ __forceinline__ double length(d3 a) { return sqrt(a.x * a.x + a.y * a
 __device__ __forceinline__ d3 cross(d3 a, d3 b) {
   return d3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
-__device__ __forceinline__ d3 normalize(d3 a) {
-  double l = length(a);
+
+// Three divisions by one denominator, bit for bit what `a.x / l, a.y / l, a.z / l` give.
+// A binary64 division is expanded by the compiler into: scale numerator and denominator
+// (v_div_scale_f64), v_rcp_f64 of the denominator refined by two Newton steps, q = n * r, one
+// correction of q by its remainder (v_div_fmas_f64), v_div_fixup_f64 for zeros, infinities and
+// NaNs. The refined reciprocal depends on the denominator alone, and whenever nothing needs
+// scaling the scale instructions return their inputs and v_div_fmas_f64 is a plain fused
+// multiply-add; so one reciprocal and the remaining four steps per numerator perform the very
+// same operations on the very same values. Nothing needs scaling when the denominator is in
+// [2^-400, 2^400) and every numerator is zero or of magnitude in [2^-900, 2^500): quotient and
+// remainder then stay in the normal range. div3_in_range assumes that; div3_by_length, for a
+// denominator that no numerator exceeds by more than a rounding error (a vector and its length),
+// checks the rest per lane and sends the lanes outside to the plain divisions.
+__device__ __forceinline__ double refined_rcp(double l) {
+  double r = __builtin_amdgcn_rcp(l);
+  double e = __builtin_fma(-l, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-l, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  return r;
+}
+__device__ __forceinline__ double div_by_rcp(double a, double l, double r) {
+  const double q = a * r;
+  const double rem = __builtin_fma(-l, q, a);
+  return __builtin_amdgcn_div_fixup(__builtin_fma(rem, r, q), l, a);
+}
+__device__ __forceinline__ d3 div3_in_range(d3 a, double l) {
+  const double r = refined_rcp(l);
+  return d3{div_by_rcp(a.x, l, r), div_by_rcp(a.y, l, r), div_by_rcp(a.z, l, r)};
+}
+__device__ __forceinline__ d3 div3_by_length(d3 a, double l) {
+  // binary exponents (0 for a zero, the true exponent for a denormal)
+  const int ex = __builtin_amdgcn_frexp_exp(a.x), ey = __builtin_amdgcn_frexp_exp(a.y), ez = __builtin_amdgcn_frexp_exp(a.z);
+  // high word of l minus that of 2^-400, against the span up to 2^400: false for infinities and
+  // NaNs too (an infinite or NaN component makes the length one)
+  const bool in_range = ((uint32_t)__double2hiint(l) - 0x26f00000u) < 0x32000000u && min(min(ex, ey), ez) >= -900;
+  if (in_range) return div3_in_range(a, l);
   return d3{a.x / l, a.y / l, a.z / l};
 }
+// src/main.rs:87-90: every component divided by the length.
+__device__ __forceinline__ d3 normalize(d3 a) { return div3_by_length(a, length(a)); }
 
 // ------------------------------------------------------------------------------------------
 // counter-based generator: draw = mix64(key + GOLDEN * ((stage << 20) + index + 1)), 52 bits
@@ -58,9 +95,19 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
   z ^= z >> 31;
   return z;
 }
-__device__ __forceinline__ uint64_t path_key(uint64_t seed, uint64_t pixel, uint64_t sample) {
-  uint64_t k = mix64(seed + RT_GOLDEN);
-  k = mix64(k + RT_GOLDEN * (pixel + 1));
+// key = mix64(mix64(mix64(seed + G) + G * (pixel + 1)) + G * (sample + 1)); the innermost term
+// depends on the seed alone and comes from the host (seed_key).
+__host__ __device__ __forceinline__ uint64_t seed_key(uint64_t seed) {
+  uint64_t z = seed + RT_GOLDEN;
+  z ^= z >> 30;
+  z *= 0xbf58476d1ce4e5b9ull;
+  z ^= z >> 27;
+  z *= 0x94d049bb133111ebull;
+  z ^= z >> 31;
+  return z;
+}
+__device__ __forceinline__ uint64_t path_key(uint64_t key0, uint64_t pixel, uint64_t sample) {
+  uint64_t k = mix64(key0 + RT_GOLDEN * (pixel + 1));
   k = mix64(k + RT_GOLDEN * (sample + 1));
   return k;
 }
@@ -73,15 +120,15 @@ struct Rng {
     return __longlong_as_double((long long)(0x3ff0000000000000ull | (mix64(x) >> 12))) - 1.0;
   }
   __device__ __forceinline__ double range(double lo, double hi) { return lo + (hi - lo) * u01(); }
-  // Two uniforms on [-1,1) from ONE draw: its high and low 32 bits, each as the top mantissa
-  // bits of a double in [1,2) (resolution 2^-31). Used for the Marsaglia candidate pairs.
+  // Two uniforms on [-1,1) from ONE draw: -1 + 2 * (h / 2^32) for its high and for its low 32 bits
+  // (resolution 2^-31). Used for the Marsaglia candidate pairs.
   __device__ __forceinline__ void pair_pm1(double& a, double& b) {
     x += RT_GOLDEN;
     const uint64_t z = mix64(x);
-    const double ua = __longlong_as_double((long long)(0x3ff0000000000000ull | ((z >> 32) << 20))) - 1.0;
-    const double ub = __longlong_as_double((long long)(0x3ff0000000000000ull | ((z & 0xffffffffull) << 20))) - 1.0;
-    a = -1.0 + 2.0 * ua;
-    b = -1.0 + 2.0 * ub;
+    // -1 + 2 * (h / 2^32) for a 32-bit half h is (h - 2^31) / 2^31, a multiple of 2^-31 below 1 in
+    // magnitude: exact in binary64 however it is evaluated, so it is evaluated the cheap way
+    a = (double)(int32_t)((uint32_t)(z >> 32) ^ 0x80000000u) * 4.656612873077392578125e-10;  // 2^-31
+    b = (double)(int32_t)((uint32_t)z ^ 0x80000000u) * 4.656612873077392578125e-10;
   }
   __device__ __forceinline__ void skip(uint32_t n) { x += RT_GOLDEN * (uint64_t)n; }
 };
@@ -503,7 +550,7 @@ __device__ __forceinline__ void shade_hit(const SceneK& sc, const ShadeIn& h, co
     if (h.slot >= 0 && m->normal_tex >= 0) {
       // NormalKind::normal_at, src/main.rs:347-378
       const uchar4 px = fetch_texel(sc.tex[m->normal_tex], tex_u, tex_v);
-      const d3 ts_normal = normalize(mk((double)px.x / 255.0, (double)px.y / 255.0, (double)px.z / 255.0));
+      const d3 ts_normal = normalize(div3_in_range(mk((double)px.x, (double)px.y, (double)px.z), 255.0));  // 0..255 over 255
       d3 t = cross(normal, mk(0.0, 1.0, 0.0));
       if (fabs(length(t)) < eps) t = cross(normal, mk(0.0, 0.0, 1.0));
       t = normalize(t);
@@ -520,7 +567,7 @@ __device__ __forceinline__ void shade_hit(const SceneK& sc, const ShadeIn& h, co
     d3 point;
     if (m->color_tex >= 0) {
       const uchar4 px = fetch_texel(sc.tex[m->color_tex], tex_u, tex_v);
-      point = mk((double)px.x / 255.0, (double)px.y / 255.0, (double)px.z / 255.0);
+      point = div3_in_range(mk((double)px.x, (double)px.y, (double)px.z), 255.0);  // 0..255 over 255
     } else {
       point = mk(m->color[0], m->color[1], m->color[2]);
     }

@@ -400,6 +400,14 @@ def quantize_rgba8(canvas, its):
     return out
 
 
+def selftest_division(n, seed=0):
+    """Runs n operand triples through the kernels' shared-reciprocal division and through plain IEEE
+    division on device 0; returns how many differ in any bit (expected 0)."""
+    bad = C.c_uint64()
+    check(lib.rt_selftest_division(int(n), int(seed), C.byref(bad)), "rt_selftest_division")
+    return bad.value
+
+
 def device_count():
     return lib.rt_device_count()
 

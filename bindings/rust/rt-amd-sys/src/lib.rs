@@ -25,6 +25,7 @@ pub const RT_FLAG_COUNT_WORK: u32 = 4;
 pub const RT_FLAG_NO_REGEN: u32 = 8;
 pub const RT_FLAG_MEGAKERNEL: u32 = 16;
 pub const RT_FLAG_PIPELINE: u32 = 32;
+pub const RT_FLAG_STORE: u32 = 64;
 
 pub const RT_TREE_HOST: u32 = 0;
 pub const RT_TREE_NONE: u32 = 1;

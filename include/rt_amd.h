@@ -67,6 +67,11 @@ extern "C" {
                               /* counters, launch log and timing accumulate. The reference's     */
                               /* display loop (src/main.rs:1099-1112) is such a run.             */
 
+#define RT_FLAG_STORE 64u     /* the pixels the call renders are overwritten with the frame (canvas  */
+                              /* = mean, sum buffer = sum) instead of added to: saves the caller a    */
+                              /* clear of a buffer it fills once per frame; other pixels (tile split) */
+                              /* are left alone                                                       */
+
 /* One per object, indexed by object index. Material::Opaque / Material::Dielectric,
  * src/main.rs:414-425; ColorKind src/main.rs:386-390; NormalKind src/main.rs:335-339. */
 typedef struct rt_material {
@@ -309,7 +314,12 @@ int rt_scene_upload(rt_scene* scene, int device);
 int rt_scene_rebuild_on_device(rt_scene* scene, int device); /* RT_BUILD_DEFAULT */
 int rt_scene_rebuild_on_device_with(rt_scene* scene, int device, uint32_t method);
 
-/* Batch Scene::hit, src/main.rs:776-814. org3/dir3 are [n][3]; dir need not be unit length. */
+/* Batch Scene::hit, src/main.rs:776-814. org3/dir3 are [n][3]; dir need not be unit length.
+ * The result is the nearest hit of the exhaustive binary64 test over every triangle and sphere.
+ * Two cases can differ from the Rust binary, whose candidates come from crate bvh 0.6.0: of two
+ * triangles at exactly equal distance the one with the lower flat index wins here (the reference
+ * keeps the first in the crate's traversal order, src/main.rs:791), and a grazing hit that the
+ * crate's binary32 boxes and ray (src/main.rs:621, 777) cull is still found here. */
 int rt_trace(rt_scene* scene, const double* org3, const double* dir3, size_t n, rt_hit* out);
 
 /* Nearest hit of the pixel-centre camera ray of every pixel (render's ray set-up,
@@ -324,7 +334,12 @@ int rt_render_accumulate(rt_scene* scene, const rt_render_params* p, double* can
 
 /* Same with the canvas in device memory and the work queued on `stream` (a hipStream_t, NULL
  * for the default stream); returns without waiting. The scene remembers the stream (later calls
- * and rt_scene_wait synchronise with it), so it must outlive the scene's next call. */
+ * and rt_scene_wait synchronise with it: a call on another stream starts behind what the previous
+ * call queued), so it must outlive the scene's next call.
+ * The sizes of the launches over the ray queue are decided on the device; the first frame of a
+ * new shape (image size, samples, tile split, depth cap) is the exception: there the host waits
+ * for the queue counts between launches to learn how many launches such a frame takes. Callers
+ * that must not block (graph capture) render one frame of the shape beforehand. */
 int rt_render_device(rt_scene* scene, const rt_render_params* p, double* device_canvas, void* stream);
 
 /* No counterpart in the reference. rt_render_device for callers that cannot allocate (code under
@@ -357,7 +372,9 @@ int rt_scene_wait(rt_scene* scene);
 int rt_scene_stream_wait(rt_scene* scene, void* stream);
 
 /* Waits for the scene's queued work, then reports (for a run of pipelined calls: the run's
- * totals; the work of the overlapped tails is reported in total on the last tail of the log). */
+ * totals). The launch log is bounded: a run keeps its latest few thousand launches one by one and
+ * folds older ones into one entry per kind (rt_launch_info.folded); events and counter snapshots
+ * are reused once read, so a frame loop may run for any length of time. */
 int rt_scene_last_stats(rt_scene* scene, rt_stats* out);
 int rt_scene_last_timing(rt_scene* scene, rt_timing* out);
 /* Per-launch log of the last render call: copies up to `capacity` entries, *n_out = total. */
@@ -368,10 +385,13 @@ int rt_scene_last_launches(rt_scene* scene, rt_launch_info* out, uint32_t capaci
 /* The reference is one process (main, src/main.rs:1054-1128) and spreads render's pixels and
  * samples over whatever the machine has (rayon, src/main.rs:988, 994). A group does the same
  * over several GPUs of a node for such a caller: every member holds its own copy of the scene
- * in its own HBM and renders its share of the frame on a host thread of its own; the first
- * member's GPU then reads the others' binary32 sums directly over xGMI (peer access, no staging
- * copies, every link into that GPU used at once) and adds the frame to the canvas. Callers that
- * run one process per GPU use rt_render_sum_f32_device and their own collective instead. */
+ * in its own HBM; the calling thread queues every member's share of the frame on that member's
+ * stream (a render call only queues work) and the GPUs run them side by side; behind them, ordered
+ * by events, the first member's GPU reads the others' binary32 sums directly over xGMI (peer
+ * access, no staging copies, every link into that GPU used at once) and adds the frame to the
+ * canvas. Callers that run one process per GPU use rt_render_sum_f32_device and their own
+ * collective instead. RT_GROUP_LOG=1 in the environment prints which devices the first one
+ * reaches by peer access when a group is created. */
 typedef struct rt_group rt_group;
 #define RT_GROUP_MAX 16u
 #define RT_SPLIT_SAMPLES 0u /* member g renders samples [g*spp/n, (g+1)*spp/n) of every pixel    */
@@ -394,11 +414,14 @@ int rt_group_size(const rt_group* group, uint32_t* n_members);
  * about 1e-7 relative, not bit for bit. Returns when the canvas is complete. */
 int rt_group_render_accumulate(rt_group* group, const rt_render_params* p, uint32_t split, double* canvas,
                                uint64_t* rays_out);
-/* Same with the canvas in the memory of the group's first device. */
+/* Same with the canvas in the memory of the group's first device. The call first waits for
+ * everything queued on that device (a clear of the canvas on a stream of the caller's, say), so
+ * the combination cannot overtake it. */
 int rt_group_render_device(rt_group* group, const rt_render_params* p, uint32_t split, double* device_canvas,
                            uint64_t* rays_out);
 /* What member `member` did in the last frame: its device, the nearest-hit queries it answered
- * and the wall-clock time its share took — the load balance of the split. */
+ * and the time its share took on its GPU (between two events on the member's stream) — the load
+ * balance of the split. */
 int rt_group_member_info(const rt_group* group, uint32_t member, int* device, uint64_t* rays, double* ms);
 
 /* impl Into<Rgba<u8>> for RGBA, src/main.rs:29-37, applied to canvas / its as the display loop

@@ -27,6 +27,7 @@ RT_FLAG_COUNT_WORK = 4
 RT_FLAG_NO_REGEN = 8
 RT_FLAG_MEGAKERNEL = 16
 RT_FLAG_PIPELINE = 32
+RT_FLAG_STORE = 64
 
 RT_TREE_HOST = 0
 RT_TREE_NONE = 1

@@ -107,6 +107,8 @@ struct DeviceScene {
   // Overlapped tails: when a call runs in several sample chunks, the thin tail of long paths of
   // one chunk (and that chunk's resolve) runs on a side stream while the next chunk starts.
   hipStream_t side = nullptr;
+  hipStream_t own = nullptr;   // stream of the entry points that take host buffers (never the device's null stream:
+                               // waiting on that one stalls every other stream of the process)
   hipEvent_t ev_gathered[2] = {nullptr, nullptr};  // main stream: chunk's tail input is complete
   hipEvent_t ev_resolved[2] = {nullptr, nullptr};  // side stream: chunk's samples have been summed
   hipEvent_t ev_join[2] = {nullptr, nullptr};      // rt_scene_stream_wait: caller's stream, side stream; re-recorded per call
@@ -197,7 +199,10 @@ static void* arena_take(Arena* a, size_t n) {
 void rt_device_scene_free(DeviceScene* d) {
   if (!d) return;
   if (d->device >= 0) (void)hipSetDevice(d->device);
-  (void)hipDeviceSynchronize();
+  // wait for the scene's own work only (its streams and the caller's last one), not for the whole device
+  if (d->last_stream_valid) (void)hipStreamSynchronize(d->last_stream);
+  if (d->side) (void)hipStreamSynchronize(d->side);
+  if (d->own) (void)hipStreamSynchronize(d->own);
   for (void* p : d->allocs) (void)hipFree(p);
   if (d->samples) (void)hipFree(d->samples);
   if (d->totals) (void)hipFree(d->totals);
@@ -206,6 +211,7 @@ void rt_device_scene_free(DeviceScene* d) {
   if (d->plans) (void)hipFree(d->plans);
   if (d->host_log) (void)hipHostFree(d->host_log);
   if (d->side) (void)hipStreamDestroy(d->side);
+  if (d->own) (void)hipStreamDestroy(d->own);
   for (int q = 0; q < 2; ++q)
     if (d->ev_join[q]) (void)hipEventDestroy(d->ev_join[q]);
   for (int q = 0; q < 2; ++q) {
@@ -330,7 +336,7 @@ int rt_device_scene_upload_from(const rt_scene* s, rt_scene* target, int device)
     return fail(RT_ERR_HIP);
   }
   std::memset(d->host_log, 0, (size_t)RT_PLAN_SLOTS * sizeof(LogRec));
-  if (hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking) != hipSuccess) {
+  if (hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&d->own, hipStreamNonBlocking) != hipSuccess) {
     rt_set_error("rt_scene_upload: hipStreamCreate failed");
     return fail(RT_ERR_HIP);
   }
@@ -1193,7 +1199,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_gather(QueueView in, QueueView out
 // mean is added to the canvas (src/main.rs:1029-1037), or the plain sum to an f32 buffer.
 __global__ __launch_bounds__(RT_BLOCK) void k_resolve(TileMap tm, const double* __restrict__ samples, uint32_t n_paths, uint32_t spp,
                                                       double* __restrict__ totals, int first_chunk, int last_chunk, double divisor,
-                                                      double* __restrict__ canvas, float* __restrict__ sum_f32) {
+                                                      double* __restrict__ canvas, float* __restrict__ sum_f32, int store) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // tile * 64 + pixel-in-tile
   const uint64_t n_pix = (uint64_t)tm.n_tiles * 64u;
   if (i >= n_pix) return;
@@ -1221,14 +1227,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(TileMap tm, const double* 
   }
   const size_t pix = ((size_t)y * tm.width + x) * 3;
   if (canvas) {
-    canvas[pix + 0] += tr / divisor;
-    canvas[pix + 1] += tg / divisor;
-    canvas[pix + 2] += tb / divisor;
+    canvas[pix + 0] = (store ? 0.0 : canvas[pix + 0]) + tr / divisor;
+    canvas[pix + 1] = (store ? 0.0 : canvas[pix + 1]) + tg / divisor;
+    canvas[pix + 2] = (store ? 0.0 : canvas[pix + 2]) + tb / divisor;
   }
   if (sum_f32) {
-    sum_f32[pix + 0] += (float)tr;
-    sum_f32[pix + 1] += (float)tg;
-    sum_f32[pix + 2] += (float)tb;
+    sum_f32[pix + 0] = (store ? 0.0f : sum_f32[pix + 0]) + (float)tr;
+    sum_f32[pix + 1] = (store ? 0.0f : sum_f32[pix + 1]) + (float)tg;
+    sum_f32[pix + 2] = (store ? 0.0f : sum_f32[pix + 2]) + (float)tb;
   }
 }
 
@@ -1746,7 +1752,7 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
     const uint32_t rgrid = (uint32_t)((n_pix + RT_BLOCK - 1) / RT_BLOCK);
     if ((rc = begin_launch(4, (uint32_t)n_pix, resolve_on)) != RT_OK) return rc;
     hipLaunchKernelGGL(k_resolve, dim3(rgrid), dim3(RT_BLOCK), 0, resolve_on, tm, samples, pp.n_paths, pp.spp, totals,
-                       (int)(c == 0), (int)(c + 1 == n_chunks), divisor, d_canvas, d_sum);
+                       (int)(c == 0), (int)(c + 1 == n_chunks), divisor, d_canvas, d_sum, (int)((p->flags & RT_FLAG_STORE) != 0));
     if ((rc = end_launch(resolve_on)) != RT_OK) return rc;
     if (handoff) {
       HIP_TRY(hipEventRecord(d->ev_resolved[par], d->side));
@@ -1814,16 +1820,16 @@ static int rt_render_accumulate_body(rt_scene* s, const rt_render_params* p, dou
     HIP_TRY(hipHostMalloc(&d->host_stage, bytes, hipHostMallocDefault));
     d->host_stage_bytes = bytes;
   }
-  HIP_TRY(hipMemsetAsync(d->stage, 0, bytes, nullptr));
-  rc = render_impl(s, p, (double*)d->stage, nullptr, nullptr, "rt_render_accumulate");
+  HIP_TRY(hipMemsetAsync(d->stage, 0, bytes, d->own));
+  rc = render_impl(s, p, (double*)d->stage, nullptr, d->own, "rt_render_accumulate");
   if (rc != RT_OK) return rc;
-  if ((rc = finish_run(d)) != RT_OK) return rc;
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(d->host_stage, d->stage, bytes, hipMemcpyDeviceToHost));
+  if ((rc = finish_run(d)) != RT_OK) return rc;  // waits for the scene's streams
+  HIP_TRY(hipMemcpyAsync(d->host_stage, d->stage, bytes, hipMemcpyDeviceToHost, d->own));
+  HIP_TRY(hipStreamSynchronize(d->own));
   rt_add_into(canvas, static_cast<const double*>(d->host_stage), bytes / sizeof(double));
   if (rays_out) {
     CounterSums cs;
-    if ((rc = read_call_counters(d, nullptr, &cs)) != RT_OK) return rc;
+    if ((rc = read_call_counters(d, d->own, &cs)) != RT_OK) return rc;
     *rays_out = cs.w[CNT_RAYS];
   }
   return RT_OK;
@@ -1846,23 +1852,22 @@ static int rt_trace_body(rt_scene* s, const double* org3, const double* dir3, si
     return RT_ERR_INVALID;
   }
   DeviceScene* d = s->dev;
-  if ((rc = finish_run(d)) != RT_OK) return rc;
-  HIP_TRY(hipDeviceSynchronize());
+  if ((rc = finish_run(d)) != RT_OK) return rc;  // waits for the scene's streams
   const size_t ray_bytes = n * 3 * sizeof(double), hit_bytes = n * sizeof(rt_hit);
   if ((rc = ensure_bytes(&d->stage, &d->stage_bytes, 2 * ray_bytes + hit_bytes)) != RT_OK) return rc;
   double* d_org = (double*)d->stage;
   double* d_dir = d_org + n * 3;
   rt_hit* d_hit = (rt_hit*)(d_dir + n * 3);
-  HIP_TRY(hipMemcpy(d_org, org3, ray_bytes, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_dir, dir3, ray_bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpyAsync(d_org, org3, ray_bytes, hipMemcpyHostToDevice, d->own));
+  HIP_TRY(hipMemcpyAsync(d_dir, dir3, ray_bytes, hipMemcpyHostToDevice, d->own));
   d->cur_counters = d->counters;
-  HIP_TRY(hipMemset(d->counters, 0, RT_COUNTER_BYTES));
+  HIP_TRY(hipMemsetAsync(d->counters, 0, RT_COUNTER_BYTES, d->own));
   const uint32_t grid = (uint32_t)((n + RT_BLOCK - 1) / RT_BLOCK);
-  hipLaunchKernelGGL((k_trace<true>), dim3(grid), dim3(RT_BLOCK), stack_lds_bytes(d), nullptr, d->k, d_org, d_dir, n, d_hit, d->counters);
+  hipLaunchKernelGGL((k_trace<true>), dim3(grid), dim3(RT_BLOCK), stack_lds_bytes(d), d->own, d->k, d_org, d_dir, n, d_hit, d->counters);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(out, d_hit, hit_bytes, hipMemcpyDeviceToHost));
-  d->last_stream = nullptr;
+  HIP_TRY(hipMemcpyAsync(out, d_hit, hit_bytes, hipMemcpyDeviceToHost, d->own));
+  HIP_TRY(hipStreamSynchronize(d->own));
+  d->last_stream = d->own;
   d->last_stream_valid = true;
   d->side_used = false;
   return RT_OK;
@@ -1881,8 +1886,7 @@ static int rt_primary_hits_body(rt_scene* s, const rt_render_params* p, int32_t*
     return RT_ERR_INVALID;
   }
   DeviceScene* d = s->dev;
-  if ((rc = finish_run(d)) != RT_OK) return rc;
-  HIP_TRY(hipDeviceSynchronize());
+  if ((rc = finish_run(d)) != RT_OK) return rc;  // waits for the scene's streams
   const size_t npix = (size_t)p->width * p->height;
   const size_t bytes = npix * (2 * sizeof(int32_t) + 3 * sizeof(double));
   if ((rc = ensure_bytes(&d->stage, &d->stage_bytes, bytes)) != RT_OK) return rc;
@@ -1896,17 +1900,17 @@ static int rt_primary_hits_body(rt_scene* s, const rt_render_params* p, int32_t*
   q.dof_strength = 0.0;
   CameraK cam = make_camera(&q);
   d->cur_counters = d->counters;
-  HIP_TRY(hipMemset(d->counters, 0, RT_COUNTER_BYTES));
+  HIP_TRY(hipMemsetAsync(d->counters, 0, RT_COUNTER_BYTES, d->own));
   const uint32_t grid = (uint32_t)((npix + RT_BLOCK - 1) / RT_BLOCK);
-  hipLaunchKernelGGL(k_primary, dim3(grid), dim3(RT_BLOCK), stack_lds_bytes(d), nullptr, d->k, cam, d_obj, d_tri, d_t, d_u, d_v, d->counters);
+  hipLaunchKernelGGL(k_primary, dim3(grid), dim3(RT_BLOCK), stack_lds_bytes(d), d->own, d->k, cam, d_obj, d_tri, d_t, d_u, d_v, d->counters);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(t, d_t, npix * sizeof(double), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(u, d_u, npix * sizeof(double), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(v, d_v, npix * sizeof(double), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(obj, d_obj, npix * sizeof(int32_t), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(tri, d_tri, npix * sizeof(int32_t), hipMemcpyDeviceToHost));
-  d->last_stream = nullptr;
+  HIP_TRY(hipMemcpyAsync(t, d_t, npix * sizeof(double), hipMemcpyDeviceToHost, d->own));
+  HIP_TRY(hipMemcpyAsync(u, d_u, npix * sizeof(double), hipMemcpyDeviceToHost, d->own));
+  HIP_TRY(hipMemcpyAsync(v, d_v, npix * sizeof(double), hipMemcpyDeviceToHost, d->own));
+  HIP_TRY(hipMemcpyAsync(obj, d_obj, npix * sizeof(int32_t), hipMemcpyDeviceToHost, d->own));
+  HIP_TRY(hipMemcpyAsync(tri, d_tri, npix * sizeof(int32_t), hipMemcpyDeviceToHost, d->own));
+  HIP_TRY(hipStreamSynchronize(d->own));
+  d->last_stream = d->own;
   d->last_stream_valid = true;
   d->side_used = false;
   return RT_OK;

@@ -3,8 +3,10 @@
 // The reference is a single process whose render (src/main.rs:977-1039) spreads independent
 // pixels and samples over the machine's cores (rayon, src/main.rs:988, 994). A caller shaped
 // like that reaches the GPUs of a node through a group: one member per GPU, each with its own
-// copy of the read-only scene in its own HBM, its own stream and — because a render call reads
-// its queue counters back between bounces — its own host thread for the length of a frame.
+// copy of the read-only scene in its own HBM and its own stream. A render call only queues work
+// (its launch extents are decided on the device), so the calling thread queues every member's
+// share one after the other and the GPUs run them side by side; events, not host threads, order
+// the combination behind the members.
 //
 // Exchange step. Every member leaves a binary32 [H][W][3] sum of its samples in its own HBM.
 // The GPUs of a node are fully connected by xGMI links, so instead of a ring the first member's
@@ -16,10 +18,10 @@
 
 #include <hip/hip_runtime.h>
 
-#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <memory>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "rt_types.h"
@@ -62,11 +64,10 @@ struct Member {
   rt_scene view;  // no host arrays: only the device half, uploaded from the caller's scene
   int device = -1;
   hipStream_t stream = nullptr;
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr;  // around the member's share of a frame, on its stream
   float* sum = nullptr;
   size_t sum_bytes = 0;
   // last frame
-  int rc = RT_OK;
-  std::string error;
   uint64_t rays = 0;
   double ms = 0.0;
 };
@@ -89,6 +90,8 @@ static void group_free(rt_group* g) {
     if (m->view.dev) rt_device_scene_free(m->view.dev);
     m->view.dev = nullptr;
     if (m->sum) (void)hipFree(m->sum);
+    if (m->ev_begin) (void)hipEventDestroy(m->ev_begin);
+    if (m->ev_end) (void)hipEventDestroy(m->ev_end);
     if (m->stream) (void)hipStreamDestroy(m->stream);
   }
   if (g->stage && !g->members.empty()) {
@@ -122,13 +125,27 @@ static int rt_group_create_body(const rt_scene* scene, const int* devices, uint3
   // the first device must be able to read every other member's memory
   const int root = devices[0];
   HIP_TRY(hipSetDevice(root));
+  // RT_GROUP_LOG=1 prints which members the first device reaches and how; RT_GROUP_NO_PEER=i makes
+  // member i count as unreachable (to exercise the failure path on any machine)
+  const char* log_env = std::getenv("RT_GROUP_LOG");
+  const bool log = log_env && *log_env && *log_env != '0';
+  const char* inject_env = std::getenv("RT_GROUP_NO_PEER");
+  const long inject = inject_env && *inject_env ? std::atol(inject_env) : -1;
   for (uint32_t i = 1; i < n; ++i) {
-    if (devices[i] == root) continue;
+    if ((long)i == inject) {
+      rt_set_error("rt_group_create: device %d cannot access the memory of device %d (member %u, RT_GROUP_NO_PEER)", root, devices[i], i);
+      return RT_ERR_HIP;
+    }
+    if (devices[i] == root) {
+      if (log) std::fprintf(stderr, "rt_group: member %u on device %d shares the first member's device\n", i, devices[i]);
+      continue;
+    }
     bool seen = false;
     for (uint32_t j = 1; j < i; ++j) seen = seen || devices[j] == devices[i];
     if (seen) continue;
     int can = 0;
     HIP_TRY(hipDeviceCanAccessPeer(&can, root, devices[i]));
+    if (log) std::fprintf(stderr, "rt_group: device %d -> device %d (member %u): peer access %s\n", root, devices[i], i, can ? "yes" : "NO");
     if (!can) {
       rt_set_error("rt_group_create: device %d cannot access the memory of device %d", root, devices[i]);
       return RT_ERR_HIP;
@@ -148,8 +165,9 @@ static int rt_group_create_body(const rt_scene* scene, const int* devices, uint3
     int rc = rt_device_scene_upload_from(scene, &m->view, devices[i]);  // leaves devices[i] current
     if (rc == RT_OK) {
       m->device = devices[i];
-      if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
-        rt_set_error("rt_group_create: hipStreamCreate on device %d failed", devices[i]);
+      if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&m->ev_begin) != hipSuccess ||
+          hipEventCreate(&m->ev_end) != hipSuccess) {
+        rt_set_error("rt_group_create: hipStreamCreate / hipEventCreate on device %d failed", devices[i]);
         rc = RT_ERR_HIP;
       }
     }
@@ -189,35 +207,6 @@ extern "C" int rt_group_member_info(const rt_group* group, uint32_t member, int*
   return RT_OK;
 }
 
-// One member's share of a frame, on its own host thread. Errors are kept in the member: the
-// library's error text is per thread.
-static void member_frame(Member* m, rt_render_params mp, size_t sum_bytes) {
-  const auto t0 = std::chrono::steady_clock::now();
-  m->rays = 0;
-  m->error.clear();
-  auto fail = [&](int rc, const char* what) {
-    m->rc = rc;
-    m->error = what ? what : rt_last_error();
-  };
-  m->rc = RT_OK;
-  if (hipSetDevice(m->device) != hipSuccess) return fail(RT_ERR_HIP, "hipSetDevice failed");
-  if (m->sum_bytes < sum_bytes) {
-    if (m->sum) (void)hipFree(m->sum);
-    m->sum = nullptr;
-    m->sum_bytes = 0;
-    if (hipMalloc((void**)&m->sum, sum_bytes) != hipSuccess) return fail(RT_ERR_HIP, "hipMalloc of a member's sum buffer failed");
-    m->sum_bytes = sum_bytes;
-  }
-  if (hipMemsetAsync(m->sum, 0, sum_bytes, m->stream) != hipSuccess) return fail(RT_ERR_HIP, "hipMemsetAsync failed");
-  int rc = rt_render_sum_f32_device(&m->view, &mp, m->sum, m->stream);
-  if (rc != RT_OK) return fail(rc, nullptr);
-  rt_stats st;
-  if ((rc = rt_scene_last_stats(&m->view, &st)) != RT_OK) return fail(rc, nullptr);  // waits for the member's work
-  if (hipStreamSynchronize(m->stream) != hipSuccess) return fail(RT_ERR_HIP, "hipStreamSynchronize failed");
-  m->rays = st.rays;
-  m->ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-}
-
 static int group_render(rt_group* g, const rt_render_params* p, uint32_t split, double* device_canvas, uint64_t* rays_out,
                         const char* who) {
   if (!g || !p || !device_canvas) {
@@ -249,11 +238,19 @@ static int group_render(rt_group* g, const rt_render_params* p, uint32_t split, 
   const uint64_t n_elems = (uint64_t)p->width * p->height * 3u;
   const size_t sum_bytes = (size_t)n_elems * sizeof(float);
 
-  std::vector<std::thread> threads;
-  threads.reserve(n);
+  // Whatever the caller did to the canvas before this call (a clear on a stream of its own, say)
+  // must be done before the combination adds to it.
+  Member& root = *g->members[0];
+  HIP_TRY(hipSetDevice(root.device));
+  HIP_TRY(hipDeviceSynchronize());
+
+  // queue every member's share; each render call returns as soon as its launches are queued (the
+  // first frame of a new shape excepted: there the host watches the queue counts once)
   for (uint32_t i = 0; i < n; ++i) {
+    Member& m = *g->members[i];
     rt_render_params mp = *p;
     mp.flags &= ~RT_FLAG_PIPELINE;
+    mp.flags |= RT_FLAG_STORE;  // the member's buffer takes the frame's sums as they are: no clear
     mp.spp_total = total;
     if (split == RT_SPLIT_SAMPLES) {
       const uint32_t lo = (uint32_t)(((uint64_t)p->spp * i) / n), hi = (uint32_t)(((uint64_t)p->spp * (i + 1)) / n);
@@ -265,28 +262,33 @@ static int group_render(rt_group* g, const rt_render_params* p, uint32_t split, 
       mp.tile_rank = i;
       mp.tile_ranks = n;
     }
-    try {
-      threads.emplace_back(member_frame, g->members[i].get(), mp, sum_bytes);
-    } catch (...) {  // no thread to be had: let the members already started finish, then report
-      for (std::thread& t : threads) t.join();
-      throw;
+    HIP_TRY(hipSetDevice(m.device));
+    if (m.sum_bytes < sum_bytes) {
+      if (m.sum) (void)hipFree(m.sum);
+      m.sum = nullptr;
+      m.sum_bytes = 0;
+      HIP_TRY(hipMalloc((void**)&m.sum, sum_bytes));
+      m.sum_bytes = sum_bytes;
     }
-  }
-  for (std::thread& t : threads) t.join();
-  uint64_t rays = 0;
-  for (uint32_t i = 0; i < n; ++i) {
-    const Member& m = *g->members[i];
-    if (m.rc != RT_OK) {
-      rt_set_error("%s: member %u (device %d): %s", who, i, m.device, m.error.c_str());
-      return m.rc;
+    HIP_TRY(hipEventRecord(m.ev_begin, m.stream));
+    // a member without samples of its own (more members than samples) contributes zeros
+    if (mp.spp == 0 && split == RT_SPLIT_SAMPLES) HIP_TRY(hipMemsetAsync(m.sum, 0, sum_bytes, m.stream));
+    const int rc = rt_render_sum_f32_device(&m.view, &mp, m.sum, m.stream);
+    if (rc != RT_OK) {
+      const std::string why = rt_last_error();
+      rt_set_error("%s: member %u (device %d): %s", who, i, m.device, why.c_str());
+      for (uint32_t j = 0; j < i; ++j) {  // let what is already queued run out before reporting
+        (void)hipSetDevice(g->members[j]->device);
+        (void)hipStreamSynchronize(g->members[j]->stream);
+      }
+      return rc;
     }
-    rays += m.rays;
+    HIP_TRY(hipEventRecord(m.ev_end, m.stream));
   }
-  if (rays_out) *rays_out = rays;
 
-  // every member's sums are complete and visible; combine on the first device
-  Member& root = *g->members[0];
+  // combine on the first device, behind every member's share
   HIP_TRY(hipSetDevice(root.device));
+  for (uint32_t i = 1; i < n; ++i) HIP_TRY(hipStreamWaitEvent(root.stream, g->members[i]->ev_end, 0));
   SumTable t{};
   for (uint32_t i = 0; i < n; ++i) t.sum[i] = g->members[i]->sum;
   // a single member in tile mode owns every tile; n == 1 needs no owner arithmetic either way
@@ -297,6 +299,23 @@ static int group_render(rt_group* g, const rt_render_params* p, uint32_t split, 
                      (double)total, device_canvas);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(root.stream));
+
+  // the frame is complete: what each member did
+  uint64_t rays = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    Member& m = *g->members[i];
+    HIP_TRY(hipSetDevice(m.device));
+    rt_stats st;
+    const int rc = rt_scene_last_stats(&m.view, &st);
+    if (rc != RT_OK) return rc;
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, m.ev_begin, m.ev_end));
+    m.rays = st.rays;
+    m.ms = ms;
+    rays += m.rays;
+  }
+  if (rays_out) *rays_out = rays;
+  HIP_TRY(hipSetDevice(root.device));
   return RT_OK;
 }
 
@@ -332,8 +351,7 @@ static int rt_group_render_accumulate_body(rt_group* g, const rt_render_params* 
   }
   // as rt_render_accumulate does: the frame alone crosses PCIe, once, into pinned memory, and is
   // added to the caller's canvas on the host (0 + x = x: the same bits as adding on the device)
-  HIP_TRY(hipMemset(g->stage, 0, bytes));
-  HIP_TRY(hipDeviceSynchronize());  // the members' streams do not wait for the default stream
+  HIP_TRY(hipMemset(g->stage, 0, bytes));  // group_render waits for the device before it queues anything
   const int rc = group_render(g, p, split, g->stage, rays_out, "rt_group_render_accumulate");
   if (rc != RT_OK) return rc;
   HIP_TRY(hipMemcpy(g->host_stage, g->stage, bytes, hipMemcpyDeviceToHost));

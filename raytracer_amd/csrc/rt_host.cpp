@@ -72,11 +72,7 @@ static void split_ws(const char* s, size_t n, std::vector<std::string>& out) {
   }
 }
 
-static bool parse_f64(const std::string& t, double* v) {
-  char* end = nullptr;
-  *v = std::strtod(t.c_str(), &end);
-  return end && *end == '\0' && end != t.c_str();
-}
+static bool parse_f64(const std::string& t, double* v) { return rt_parse_f64(t, v); }
 
 // "12", "12/5", "12/5/7" -> the integers between the slashes.
 static bool parse_face_item(const std::string& t, std::vector<uint64_t>& out) {
@@ -86,10 +82,9 @@ static bool parse_face_item(const std::string& t, std::vector<uint64_t>& out) {
     size_t e = t.find('/', b);
     std::string piece = t.substr(b, e == std::string::npos ? std::string::npos : e - b);
     if (piece.empty()) return false;
-    char* end = nullptr;
-    unsigned long long v = std::strtoull(piece.c_str(), &end, 10);
-    if (!end || *end != '\0') return false;
-    out.push_back((uint64_t)v);
+    uint64_t v = 0;
+    if (!rt_parse_u64(piece, &v)) return false;
+    out.push_back(v);
     if (e == std::string::npos) break;
     b = e + 1;
   }

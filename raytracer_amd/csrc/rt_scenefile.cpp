@@ -65,9 +65,7 @@ struct Parser {
   }
   bool number(double* v) {
     if (!more()) return false;
-    char* end = nullptr;
-    *v = std::strtod(tok[at].c_str(), &end);
-    if (!end || *end != '\0' || end == tok[at].c_str()) return false;
+    if (!rt_parse_f64(tok[at], v)) return false;
     ++at;
     return true;
   }

@@ -138,6 +138,29 @@ static inline int rt_guard(const char* who, F&& body) noexcept {
     return RT_ERR_INVALID;
   }
 }
+// Number parsing that does not depend on the process locale (strtod does: a host that has called
+// setlocale with a comma decimal point could load no asset) and accepts what Rust's str::parse
+// accepts (src/main.rs:1147, 1161): decimal notation with an optional sign and exponent, "inf",
+// "infinity", "nan"; no hexadecimal floats, no leading or trailing junk.
+#include <charconv>
+#include <system_error>
+static inline bool rt_parse_f64(const std::string& t, double* v) {
+  const char* b = t.data();
+  const char* e = b + t.size();
+  if (b != e && *b == '+') ++b;  // from_chars takes no plus sign; Rust does
+  if (b == e || *b == '+') return false;
+  const std::from_chars_result r = std::from_chars(b, e, *v, std::chars_format::general);
+  return r.ec == std::errc() && r.ptr == e;
+}
+// An unsigned decimal integer, optionally with a plus sign (Rust's usize parse): no minus, no junk.
+static inline bool rt_parse_u64(const std::string& t, uint64_t* v) {
+  const char* b = t.data();
+  const char* e = b + t.size();
+  if (b != e && *b == '+') ++b;
+  if (b == e) return false;
+  const std::from_chars_result r = std::from_chars(b, e, *v, 10);
+  return r.ec == std::errc() && r.ptr == e && *b != '+' && *b != '-';
+}
 void rt_fill_leaf_records(rt_scene* s);
 double rt_scene_box_pad(const rt_scene* s);
 unsigned rt_build_threads();

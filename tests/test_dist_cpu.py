@@ -113,3 +113,33 @@ def test_shard_helpers_cover_every_sample_and_tile():
         assert all(p.spp == 10 and p.spp_total == 10 * world for p in pw)
         pt = [parallel.shard_tiles(base, r, world) for r in range(world)]
         assert all(p.tile_size == 64 and p.tile_ranks == world and p.tile_rank == r for r, p in enumerate(pt))
+
+
+def test_strong_sample_split_of_the_1024_spp_frame(oracle):
+    """BASELINE.json configs[3]: 1024 samples per pixel divided over 2, 4 and 8 GPUs as 512, 256 and
+    128 per GPU (bench.py --split samples_strong). The shards are exactly those blocks of each
+    pixel's sample stream, and rendering the blocks separately and adding the sums gives the frame
+    (here on the CPU restatement, at a size it finishes in seconds)."""
+    sys.path.insert(0, ROOT)
+    import numpy as np
+
+    import raytracer_amd as rt
+    from raytracer_amd import parallel
+
+    frame = rt.render_params(width=3840, height=2160, spp=1024, first_sample=0)
+    for world, each in ((2, 512), (4, 256), (8, 128)):
+        shards = [parallel.shard_samples(frame, r, world) for r in range(world)]
+        assert [(p.first_sample, p.spp, p.spp_total) for p in shards] == [(r * each, each, 1024) for r in range(world)]
+    o = oracle.OracleScene.build("sphere_floor")
+    small = rt.render_params(width=24, height=16, spp=16, first_sample=32, seed=9)
+    whole = np.zeros((16, 24, 3))
+    rays, _ = o.render(whole, small)
+    parts = np.zeros((16, 24, 3))
+    total = 0
+    for r in range(8):
+        p = parallel.shard_samples(small, r, 8)
+        assert p.spp == 2 and p.first_sample == 32 + 2 * r
+        n, _ = o.render(parts, p)  # adds (sum of the shard's samples) / spp_total
+        total += n
+    assert total == rays
+    assert np.max(np.abs(parts - whole)) < 1e-12

@@ -1,6 +1,6 @@
 """rt_group_*: one frame over several members driven from one process. The box the GPU tests run
 on has one GPU, so the members here share device 0 (the library allows that for exactly this
-purpose); what is checked is the sharding arithmetic, the threads, and the combining kernel."""
+purpose); what is checked is the sharding arithmetic, the ordering by events, and the combining kernel."""
 import numpy as np
 import pytest
 
@@ -119,3 +119,15 @@ def test_group_outlives_its_scene_and_rejects_bad_frames(spot):
         assert c.tobytes() == before.tobytes()
     with pytest.raises(_ffi.RtError):
         rt.Group(spot, [0, rt.device_count()])
+
+
+def test_a_member_the_first_device_cannot_reach_is_refused(monkeypatch):
+    """The failure path of rt_group_create (no peer access), injected: this box has one GPU."""
+    s = scenes.build("sphere_floor")
+    monkeypatch.setenv("RT_GROUP_NO_PEER", "1")
+    monkeypatch.setenv("RT_GROUP_LOG", "1")
+    with pytest.raises(_ffi.RtError) as e:
+        rt.Group(s, [0, 0])
+    assert e.value.code == _ffi.RT_ERR_HIP and "cannot access" in str(e.value)
+    monkeypatch.delenv("RT_GROUP_NO_PEER")
+    assert len(rt.Group(s, [0, 0])) == 2

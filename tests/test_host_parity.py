@@ -60,6 +60,26 @@ def test_load_obj_errors(tmp_path):
     assert rt.load_obj(ok).counts() == (4, 1, 2)
 
 
+def test_numbers_are_parsed_as_rust_parses_them(tmp_path):
+    """load_obj reads coordinates with str::parse::<f64> and indices with parse::<usize>
+    (src/main.rs:1147, 1161): decimal notation, optional sign and exponent, no hexadecimal floats,
+    no negative indices; and not through strtod, whose decimal point follows the process locale."""
+    tri = "v 0 0 0\nv 1 0 0\nv 0 1 0\n"
+    ok = tmp_path / "ok.obj"
+    ok.write_text("v +0.5 -1e-3 2.5E+1\nv 1 0 0\nv 0 1 0\nf +1 2 3\n")
+    assert rt.load_obj(ok).counts()[:2] == (3, 1)
+    for bad_line in ("v 0x1p3 0 0\n", "v 1,5 0 0\n", "v 1.5x 0 0\n", "v ++1 0 0\n", "v  \n"):
+        f = tmp_path / "bad.obj"
+        f.write_text(bad_line + tri + "f 1 2 3\n")
+        with pytest.raises(_ffi.RtError):
+            rt.load_obj(f)
+    for bad_face in ("f -1 2 3\n", "f 1 2 3x\n", "f 0x1 2 3\n", "f 1.0 2 3\n"):
+        f = tmp_path / "badf.obj"
+        f.write_text(tri + bad_face)
+        with pytest.raises(_ffi.RtError):
+            rt.load_obj(f)
+
+
 def test_scene_create_validation():
     mat = rt.Opaque((1, 1, 1), 0, 1, 0)
     tv = np.zeros((1, 3, 3)); tn = np.zeros((1, 3, 3)); tuv = np.zeros((1, 3, 2))

@@ -4,10 +4,11 @@
     python tests/golden/make_golden.py
 
 Fixtures
-  ref_screenshot_blocks_200x150.png  8x8 block means of the reference's own committed output
-                                     images/20220206_170941.png (1600x1200, sphere_scene at HEAD);
-                                     data derived from a reference data file, the only artefact
-                                     of the reference that pins the oracle end to end.
+  ref_screenshot_*blocks_*.png       8x8 block means of the reference's own committed outputs that show
+                                     sphere_scene at HEAD (images/20220206_170941, _170012, _164420
+                                     at 1600x1200, _163744 at 640x480): data derived from reference
+                                     data files, the only artefacts of the reference that pin the
+                                     oracle end to end.
   primary_<scene>_<w>x<h>.npz        primary-hit buffer of the oracle (brute-force Scene::hit on
                                      pixel-centre rays): sha256 of obj/tri/t/u/v plus a 16x16 crop.
   render_<scene>.npz                 the oracle's image (binary64 canvas) and ray count for a small
@@ -30,17 +31,29 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+# The screenshots of the reference that show sphere_scene() as it is at HEAD (the four that
+# tools/match_reference_images.py finds at correlation 0.998; no screenshot matches any other scene).
+SCREENSHOTS = {
+    "20220206_170941": "ref_screenshot_blocks_200x150.png",
+    "20220206_170012": "ref_screenshot_170012_blocks_200x150.png",
+    "20220206_164420": "ref_screenshot_164420_blocks_200x150.png",
+    "20220206_163744": "ref_screenshot_163744_blocks_80x60.png",  # 640x480
+}
+
+
 def screenshot_blocks():
     from PIL import Image
 
-    src = "/root/reference/images/20220206_170941.png"
-    if not os.path.exists(src):
-        print("skip screenshot fixture: reference not mounted")
-        return
-    im = np.asarray(Image.open(src).convert("RGB"), dtype=np.float64)  # 1200x1600x3
-    blocks = im.reshape(150, 8, 200, 8, 3).mean(axis=(1, 3))
-    Image.fromarray(np.round(blocks).astype(np.uint8)).save(os.path.join(HERE, "ref_screenshot_blocks_200x150.png"))
-    print("wrote ref_screenshot_blocks_200x150.png")
+    for stem, fixture in SCREENSHOTS.items():
+        src = f"/root/reference/images/{stem}.png"
+        if not os.path.exists(src):
+            print("skip screenshot fixtures: reference not mounted")
+            return
+        im = np.asarray(Image.open(src).convert("RGB"), dtype=np.float64)  # [h][w][3]
+        h, w, _ = im.shape
+        blocks = im.reshape(h // 8, 8, w // 8, 8, 3).mean(axis=(1, 3))
+        Image.fromarray(np.round(blocks).astype(np.uint8)).save(os.path.join(HERE, fixture))
+        print("wrote", fixture)
 
 
 def sha(a):

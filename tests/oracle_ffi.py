@@ -61,12 +61,21 @@ def register_texture(name, rgba):
     _registered.add(name)
 
 
-def register_default_textures():
-    from raytracer_amd.scenes import load_texture
+def decode_texture(path):
+    """[h][w][4] uint8 of a PNG, decoded by Pillow and not by the product's own decoder: the oracle's
+    texels must not depend on the code under test. Pillow, like the reference's image 0.23, ignores
+    the gamma and colour-profile chunks some of the files carry."""
+    from PIL import Image
 
+    Image.MAX_IMAGE_PIXELS = None  # the 20000 x 20000 texture is no decompression bomb
+    with Image.open(path) as im:
+        return np.ascontiguousarray(np.asarray(im.convert("RGBA"), dtype=np.uint8))
+
+
+def register_default_textures():
     for name in ("spot_texture.png", "ogre/diffuse.png", "ogre/normalmap.png"):
         if name not in _registered:
-            register_texture(name, load_texture(os.path.join(ASSETS, name)))
+            register_texture(name, decode_texture(os.path.join(ASSETS, name)))
 
 
 class OracleScene:
@@ -86,9 +95,7 @@ class OracleScene:
         if name == "spot_20k":  # the default scene with the 20000x20000 texture of src/main.rs:1273
             name, spot_texture = "spot", "spot_texture_20k.png"
             if spot_texture not in _registered:
-                from raytracer_amd.scenes import load_texture
-
-                register_texture(spot_texture, load_texture(os.path.join(assets, spot_texture)))
+                register_texture(spot_texture, decode_texture(os.path.join(assets, spot_texture)))
         return OracleScene(lib.orc_scene_build(name.encode(), assets.encode(), spot_texture.encode()))
 
     @staticmethod

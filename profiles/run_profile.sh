@@ -9,7 +9,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="$R/bench.py --no-cpu-baseline ${BENCH_ARGS:-}"  # bench.py's own defaults for steps and warm-up
+ARGS="$R/bench.py --no-cpu-baseline --no-secondary ${BENCH_ARGS:-}"  # bench.py's own defaults for steps and warm-up; the CPU leg and the
+# Spot 4K frames it times after the main loop are left out (they would mix another workload into the per-kernel means)
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/pmc_fetch.log 2>&1
 timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS > $OUT/pmc_write.log 2>&1

@@ -908,31 +908,46 @@ __device__ __forceinline__ uint32_t wave_reserve(unsigned long long* word, unsig
 // The same block leaves a snapshot of the cumulative work counters in host-visible memory, from
 // which the per-launch log is made once the frame is done.
 
-// One block of RT_SHARDS threads, thread t on counter line t. plan[0] = extent of the queue whose
+// One block, every thread on a few of the RT_SHARDS counter lines. plan[0] = extent of the queue whose
 // counts are words in_hit_word / in_ray_word of the first n_seg lines; with split_at > 0 also
 // plan[1] = plan[0] if the queue holds at most split_at records, else empty, and plan[2] the other
 // way round. zero_word >= 0: words zero_word, zero_word + 1 of every line are set to zero (the
 // counts of the queue the next launch appends to). log (may be null) receives the snapshot.
-__global__ __launch_bounds__(RT_SHARDS) void k_plan(unsigned long long* counters, uint32_t in_hit_word, uint32_t in_ray_word, int zero_word,
-                                                    uint32_t n_seg, uint32_t seg_cap, uint32_t split_at, PlanRec* __restrict__ plan,
-                                                    LogRec* __restrict__ log) {
-  __shared__ unsigned long long s_sum[RT_SHARDS / 64][CNT_N + 2];
-  __shared__ uint32_t s_max[RT_SHARDS / 64][3];
+#define RT_PLAN_THREADS 256
+__global__ __launch_bounds__(RT_PLAN_THREADS) void k_plan(unsigned long long* counters, uint32_t in_hit_word, uint32_t in_ray_word, int zero_word,
+                                                          uint32_t n_seg, uint32_t seg_cap, uint32_t split_at, PlanRec* __restrict__ plan,
+                                                          LogRec* __restrict__ log) {
+  constexpr int WAVES = RT_PLAN_THREADS / 64, PER = RT_SHARDS / RT_PLAN_THREADS;  // lines t, t + 256, ... per thread
+  __shared__ unsigned long long s_sum[WAVES][CNT_N + 2];
+  __shared__ uint32_t s_max[WAVES][3];
   const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63u;
-  unsigned long long* line = counters + (size_t)t * RT_LINE_WORDS;
-  uint32_t nh = 0, nr = 0;
-  if (t < n_seg) {
-    nh = (uint32_t)line[in_hit_word];
-    nr = (uint32_t)line[in_ray_word];
+  unsigned long long nh_sum = 0, nr_sum = 0;
+  uint32_t mh = 0, mr = 0, ov = 0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const uint32_t seg = t + (uint32_t)k * RT_PLAN_THREADS;
+    if (seg < n_seg) {
+      const unsigned long long* line = counters + (size_t)seg * RT_LINE_WORDS;
+      const uint32_t nh = (uint32_t)line[in_hit_word], nr = (uint32_t)line[in_ray_word];
+      nh_sum += nh;
+      nr_sum += nr;
+      mh = max(mh, nh);
+      mr = max(mr, nr);
+      ov |= (uint64_t)nh + nr > seg_cap ? 1u : 0u;
+    }
   }
   // sums of every word over the lines, and of the two counts over the segments: one word at a time
 #pragma unroll 1
   for (int w = 0; w < CNT_N + 2; ++w) {
-    unsigned long long x = w < CNT_N ? line[w] : (w == CNT_N ? (unsigned long long)nh : (unsigned long long)nr);
+    unsigned long long x = w == CNT_N ? nh_sum : nr_sum;
+    if (w < CNT_N) {
+      x = 0ull;
+#pragma unroll
+      for (int k = 0; k < PER; ++k) x += counters[(size_t)(t + (uint32_t)k * RT_PLAN_THREADS) * RT_LINE_WORDS + w];
+    }
     for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
     if (lane == 0) s_sum[wave][w] = x;
   }
-  uint32_t mh = nh, mr = nr, ov = (uint64_t)nh + nr > seg_cap ? 1u : 0u;
   for (int off = 32; off > 0; off >>= 1) {
     mh = max(mh, (uint32_t)__shfl_down((int)mh, off));
     mr = max(mr, (uint32_t)__shfl_down((int)mr, off));
@@ -945,28 +960,33 @@ __global__ __launch_bounds__(RT_SHARDS) void k_plan(unsigned long long* counters
   }
   __syncthreads();
   if (zero_word >= 0) {
-    line[zero_word] = 0ull;
-    line[zero_word + 1] = 0ull;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      unsigned long long* line = counters + (size_t)(t + (uint32_t)k * RT_PLAN_THREADS) * RT_LINE_WORDS;
+      line[zero_word] = 0ull;
+      line[zero_word + 1] = 0ull;
+    }
   }
+  // thread w adds up word w; thread 0 then has the two counts and the maxima to make the plan of
+  if (t < CNT_N + 2) {
+    unsigned long long x = 0ull;
+    for (int k = 0; k < WAVES; ++k) x += s_sum[k][t];
+    s_sum[0][t] = x;
+    if (log && t < CNT_N) log->w[t] = x;
+  }
+  __syncthreads();
   if (t == 0) {
     uint32_t max_h = 0, max_r = 0, over = 0;
-    for (int k = 0; k < RT_SHARDS / 64; ++k) {
+    for (int k = 0; k < WAVES; ++k) {
       max_h = max(max_h, s_max[k][0]);
       max_r = max(max_r, s_max[k][1]);
       over |= s_max[k][2];
     }
-#pragma unroll 1
-    for (int w = 0; w < CNT_N + 2; ++w) {  // totals land in row 0
-      unsigned long long x = 0ull;
-      for (int k = 0; k < RT_SHARDS / 64; ++k) x += s_sum[k][w];
-      s_sum[0][w] = x;
-    }
-    const unsigned long long* tot = s_sum[0];
     PlanRec pr;
     pr.hit_blocks = (max_h + RT_BLOCK - 1) / RT_BLOCK;
     pr.ray_blocks = (max_r + RT_BLOCK - 1) / RT_BLOCK;
-    pr.n_hit = (uint32_t)tot[CNT_N];
-    pr.n_ray = (uint32_t)tot[CNT_N + 1];
+    pr.n_hit = (uint32_t)s_sum[0][CNT_N];
+    pr.n_ray = (uint32_t)s_sum[0][CNT_N + 1];
     const PlanRec none{0u, 0u, 0u, 0u};
     plan[0] = pr;
     if (split_at > 0) {
@@ -975,7 +995,6 @@ __global__ __launch_bounds__(RT_SHARDS) void k_plan(unsigned long long* counters
       plan[2] = fits ? none : pr;
     }
     if (log) {
-      for (int w = 0; w < CNT_N; ++w) log->w[w] = tot[w];
       log->n_hit = pr.n_hit;
       log->n_ray = pr.n_ray;
       log->overflow = over;
@@ -1161,35 +1180,29 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
 // runs from that copy on the side stream while the main stream reuses the queues.
 __global__ __launch_bounds__(RT_BLOCK) void k_gather(QueueView in, QueueView out, const PlanRec* __restrict__ plan, int has_rad,
                                                      const unsigned long long* __restrict__ in_counters, unsigned long long* out_counters) {
+  // one workgroup per segment; it reserves room for the segment's whole front run, and for its
+  // whole back run, with one atomic each (every wave adding to the one tail word would queue up
+  // behind the ~88 atomics per microsecond a single word takes)
+  if (plan->hit_blocks + plan->ray_blocks == 0u) return;  // nothing to gather, or too much for the tail segment
   const uint32_t seg = blockIdx.x;
-  const int lane = threadIdx.x & 63;
   const unsigned long long* line = in_counters + (size_t)seg * RT_LINE_WORDS;
-  const uint32_t hit_blocks = plan->hit_blocks, vb_end = hit_blocks + plan->ray_blocks;
-  for (uint32_t vb = blockIdx.y; vb < vb_end; vb += gridDim.y) {
-    const bool ray_block = vb >= hit_blocks;
-    bool alive;
-    size_t entry;
-    if (!ray_block) {
-      const uint32_t i = vb * RT_BLOCK + threadIdx.x;
-      alive = i < (uint32_t)line[in.hit_word];
-      entry = (size_t)seg * in.seg_cap + i;
-    } else {
-      const uint32_t i = (vb - hit_blocks) * RT_BLOCK + threadIdx.x;
-      alive = i < (uint32_t)line[in.ray_word];
-      entry = (size_t)seg * in.seg_cap + (in.seg_cap - 1u - (alive ? i : 0u));
-    }
-    const unsigned long long mask = __ballot(alive);
-    if (!mask) continue;
-    const uint32_t i = wave_reserve(&out_counters[ray_block ? out.ray_word : out.hit_word], mask, lane);
-    // the plan this launch runs on is empty unless every record fits the segment; the two runs
-    // grow towards each other, so together they fit wherever they meet
-    if (!alive || i >= out.seg_cap) continue;
-    const size_t e = ray_block ? (size_t)(out.seg_cap - 1u - i) : (size_t)i;
-    queue_store(out, e, queue_load(in, entry));
-    if (has_rad) {
-      out.rad[e * 3] = in.rad[entry * 3];
-      out.rad[e * 3 + 1] = in.rad[entry * 3 + 1];
-      out.rad[e * 3 + 2] = in.rad[entry * 3 + 2];
+  for (int run = 0; run < 2; ++run) {
+    const uint32_t n = (uint32_t)line[run ? in.ray_word : in.hit_word];
+    if (n == 0u) continue;
+    unsigned int base = 0;
+    if (threadIdx.x == 0) base = atomicAdd(reinterpret_cast<unsigned int*>(&out_counters[run ? out.ray_word : out.hit_word]), n);
+    base = __shfl(base, 0);
+    for (uint32_t i = threadIdx.x; i < n; i += RT_BLOCK) {
+      const size_t entry = (size_t)seg * in.seg_cap + (run ? in.seg_cap - 1u - i : i);
+      const uint32_t o = base + i;
+      if (o >= out.seg_cap) continue;  // cannot happen: the plan is empty unless every record fits
+      const size_t e = run ? (size_t)(out.seg_cap - 1u - o) : (size_t)o;
+      queue_store(out, e, queue_load(in, entry));
+      if (has_rad) {
+        out.rad[e * 3] = in.rad[entry * 3];
+        out.rad[e * 3 + 1] = in.rad[entry * 3 + 1];
+        out.rad[e * 3 + 2] = in.rad[entry * 3 + 2];
+      }
     }
   }
 }
@@ -1564,7 +1577,7 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
       if (r != RT_OK) return r;
     }
     *seq = (int64_t)d->snap_seq++;
-    hipLaunchKernelGGL(k_plan, dim3(1), dim3(RT_SHARDS), 0, on, lines, in_hit_word, in_ray_word, zero_word, n_seg, seg_cap, split_at,
+    hipLaunchKernelGGL(k_plan, dim3(1), dim3(RT_PLAN_THREADS), 0, on, lines, in_hit_word, in_ray_word, zero_word, n_seg, seg_cap, split_at,
                        plan_at(*seq), d->host_log + ((uint64_t)*seq % RT_PLAN_SLOTS));
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -1627,6 +1640,8 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
       // the plain form did not): a few workgroups per segment
       const uint32_t seg_blocks = seg_cap / RT_BLOCK;
       const dim3 qgrid(n_seg, std::max<uint32_t>(1u, std::min<uint32_t>(seg_blocks, (grid_blocks + n_seg - 1) / n_seg)));
+      // the same for launches that normally find nothing to do (behind a grid sized from experience)
+      const dim3 cgrid(n_seg, std::max<uint32_t>(1u, std::min<uint32_t>(seg_blocks, (4096u + n_seg - 1) / n_seg)));
       // the four counts of every line start at zero (adjacent words)
       HIP_TRY(hipMemset2DAsync(counters + CNT_Q0, line_bytes, 0, 4 * sizeof(unsigned long long), RT_SHARDS, stream));
       if ((rc = begin_launch(0, pp.n_paths, stream)) != RT_OK) return rc;
@@ -1680,7 +1695,7 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
         const bool cover = sized_grid(rounds, snap, &gy);
         if ((rc = begin_launch(1, 0u, stream)) != RT_OK) return rc;
         if (gy) launch_wave<1>(count, false, dim3(n_seg, gy), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, plan_at(snap), 0u, samples, counters);
-        if (cover) launch_wave<1>(count, true, qgrid, lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, plan_at(snap), gy, samples, counters);
+        if (cover) launch_wave<1>(count, true, cgrid, lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, plan_at(snap), gy, samples, counters);
         if ((rc = end_launch(stream)) != RT_OK) return rc;
         const int64_t sized_by = snap;
         // counts of the queue just written; the counts of the one just read start the next round at zero
@@ -1698,10 +1713,10 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
         // frame; otherwise (record 1 empty, record 2 the extent) the tail runs here, in place.
         const QueueView tv{(float4*)d->tail_in[par], tail_cap, d->tail_rad[par], tail_cap, (uint32_t)(par ? CNT_Q1 : CNT_Q0), (uint32_t)(par ? CNT_R1 : CNT_R0)};
         HIP_TRY(hipMemsetAsync(d->tail_counters + tv.hit_word, 0, 2 * sizeof(unsigned long long), stream));
-        hipLaunchKernelGGL(k_gather, qgrid, dim3(RT_BLOCK), 0, stream, qv[cur], tv, (const PlanRec*)(plan_at(snap) + 1), (int)emission, counters, d->tail_counters);
+        hipLaunchKernelGGL(k_gather, dim3(n_seg), dim3(RT_BLOCK), 0, stream, qv[cur], tv, (const PlanRec*)(plan_at(snap) + 1), (int)emission, counters, d->tail_counters);
         HIP_TRY(hipGetLastError());
         if ((rc = begin_launch(2, 0u, stream)) != RT_OK) return rc;
-        launch_wave<2>(count, true, qgrid, lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, plan_at(snap) + 2, 0u, samples, counters);
+        launch_wave<2>(count, true, cgrid, lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, plan_at(snap) + 2, 0u, samples, counters);
         if ((rc = end_launch(stream)) != RT_OK) return rc;
         {
           int64_t after;
@@ -1727,7 +1742,7 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
         const bool cover = sized_grid(rounds, snap, &gy);
         if ((rc = begin_launch(2, 0u, stream)) != RT_OK) return rc;
         if (gy) launch_wave<2>(count, false, dim3(n_seg, gy), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, plan_at(snap), 0u, samples, counters);
-        if (cover) launch_wave<2>(count, true, qgrid, lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, plan_at(snap), gy, samples, counters);
+        if (cover) launch_wave<2>(count, true, cgrid, lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, plan_at(snap), gy, samples, counters);
         if ((rc = end_launch(stream)) != RT_OK) return rc;
         const int64_t sized_by = snap;
         if ((rc = take_plan(stream, counters, CNT_Q0, CNT_R0, -1, 0u, 0u, 0u, &snap)) != RT_OK) return rc;

@@ -42,6 +42,9 @@ using namespace rtk;
 #define RT_SHARDS 1024     /* counter lines; also the most queue segments a launch uses */
 #define RT_LINE_WORDS 16   /* 64-bit words per line (128 B)                             */
 #define RT_WORK_BATCH 1024 /* path indices a wave takes from the work counter at a time */
+#ifndef RT_GRID_NODES
+#define RT_GRID_NODES 1
+#endif
 #define RT_LONG_STEPS_DEFAULT 8u /* node visits from which a ray counts as long (see k_wave) */
 // words of a line
 enum { CNT_RAYS = 0, CNT_NODES, CNT_TRIS, CNT_SPHERES, CNT_SHADED, CNT_PATHS, CNT_Q0, CNT_R0, CNT_Q1, CNT_R1, CNT_WORK, CNT_WI_INNER, CNT_WI_LEAF, CNT_WI_REJECT, CNT_WAVES, CNT_N };
@@ -294,6 +297,60 @@ int rt_device_scene_upload_from(const rt_scene* s, rt_scene* target, int device)
     return code;
   };
   if ((rc = upload_array(d, s->nodes.data(), s->nodes.size(), &d->k.nodes)) != RT_OK) return fail(rc);
+  {
+    // The tree once more on a 16-bit grid over its own bounds (BvhNodeQ). A grid plane lies at
+    // least one whole step outside the binary32 plane it stands for (and never inside the grid's
+    // ends), which is thousands of times the rounding the traversal's arithmetic adds.
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (const BvhNode& n : s->nodes) {
+      const float* planes[3] = {n.bx, n.by, n.bz};
+      for (int a = 0; a < 3; ++a)
+        for (int k = 0; k < 4; ++k) {
+          const float v = planes[a][k];
+          if (!std::isfinite(v)) continue;
+          lo[a] = std::min(lo[a], v);
+          hi[a] = std::max(hi[a], v);
+        }
+    }
+    for (int a = 0; a < 3; ++a)
+      if (!(lo[a] <= hi[a])) lo[a] = hi[a] = 0.f;  // no finite plane on this axis (an empty tree)
+    std::vector<BvhNodeQ> qn(s->nodes.size());
+    for (int a = 0; a < 3; ++a) {
+      // grid: q = 1 .. 65534 span [lo, hi]; 0 and 65535 are the outward steps of the extremes
+      double step = ((double)hi[a] - (double)lo[a]) / 65533.0;
+      if (!(step > 0.0)) step = 1.0;
+      float stepf = (float)step;
+      while ((double)stepf * 65533.0 < (double)hi[a] - (double)lo[a]) stepf = std::nextafterf(stepf, INFINITY);
+      float lof = (float)((double)lo[a] - (double)stepf);
+      while ((double)lof + (double)stepf > (double)lo[a]) lof = std::nextafterf(lof, -INFINITY);
+      d->k.q_lo[a] = lof;
+      d->k.q_step[a] = stepf;
+      for (size_t i = 0; i < s->nodes.size(); ++i) {
+        const BvhNode& n = s->nodes[i];
+        const float* planes = a == 0 ? n.bx : a == 1 ? n.by : n.bz;
+        for (int k = 0; k < 4; ++k) {
+          const bool is_max = (k & 1) != 0;
+          const double v = planes[k];
+          long q;
+          if (!std::isfinite(v)) {
+            q = is_max ? 65535 : 0;  // not a finite plane: as far out as the grid goes (the box is then always entered)
+          } else if (is_max) {
+            q = (long)std::ceil((v - (double)lof) / (double)stepf) + 1;
+            while ((double)lof + (double)(q - 1) * (double)stepf < v) ++q;
+          } else {
+            q = (long)std::floor((v - (double)lof) / (double)stepf) - 1;
+            while ((double)lof + (double)(q + 1) * (double)stepf > v) --q;
+          }
+          qn[i].q[a * 4 + k] = (uint16_t)std::min(65535l, std::max(0l, q));
+        }
+      }
+    }
+    for (size_t i = 0; i < s->nodes.size(); ++i) {
+      qn[i].child[0] = s->nodes[i].child[0];
+      qn[i].child[1] = s->nodes[i].child[1];
+    }
+    if ((rc = upload_array(d, qn.data(), qn.size(), &d->k.qnodes)) != RT_OK) return fail(rc);
+  }
   if ((rc = upload_array(d, s->tri_geom.data(), s->tri_geom.size(), &d->k.geom)) != RT_OK) return fail(rc);
   if ((rc = upload_array(d, s->tri_shade.data(), s->tri_shade.size(), &d->k.shade)) != RT_OK) return fail(rc);
   if ((rc = upload_array(d, s->spheres.data(), s->spheres.size(), &d->k.spheres)) != RT_OK) return fail(rc);
@@ -1095,8 +1152,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
   for (;;) {
     if (alive) {
       Trav t;
-      trav_begin(t, sc, o, dir, stk);
-      trav_run<COUNT>(t, sc, stride, wc);
+      // the launches over the queue walk the half-size copy of the tree (see BvhNodeQ)
+      trav_begin<STAGE != 0 && RT_GRID_NODES>(t, sc, o, dir, stk);
+      trav_run<COUNT, STAGE != 0 && RT_GRID_NODES>(t, sc, stride, wc);
       steps = t.steps;
       wc.rays++;
       finish_hit<COUNT>(sc, o, dir, t.best_t, t.best_u, t.best_v, t.best_slot, h, wc);

@@ -153,6 +153,8 @@ __device__ __forceinline__ d3 random_unit_sphere_surface(Rng& r) {
 // ------------------------------------------------------------------------------------------
 struct SceneK {
   const BvhNode* nodes;
+  const BvhNodeQ* qnodes;  // the same tree on the 16-bit grid
+  float q_lo[3], q_step[3];
   const TriGeom* geom;
   const TriShade* shade;
   const SphereRec* spheres;
@@ -232,7 +234,7 @@ __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elemen
 // Per-lane traversal state (the stack lives in LDS, one column per lane).
 struct Trav {
   d3 o, d;
-  float ix, iy, iz;                                 // reciprocal direction
+  float ix, iy, iz;                                 // reciprocal direction (grid nodes: grid step * reciprocal direction)
   float mx_lo, mx_hi, my_lo, my_hi, mz_lo, mz_hi;   // -(o -+ pad) * reciprocal direction
   float best32k;                                    // pruning distance for the f32 box tests
   double best_t, best_u, best_v;
@@ -244,7 +246,8 @@ struct Trav {
 
 // Culling ray: t = b * inv - (o -+ pad) * inv, one fused operation per plane (culling only; the
 // fused rounding perturbs the padded origin by less than the pad already allows for).
-__device__ __forceinline__ void trav_set_ray(Trav& t, const d3 o, const d3 d) {
+template <bool QUANT>
+__device__ __forceinline__ void trav_set_ray(Trav& t, const SceneK& sc, const d3 o, const d3 d) {
   t.o = o;
   t.d = d;
   const double omax = fmax(fabs(o.x), fmax(fabs(o.y), fabs(o.z)));
@@ -267,10 +270,25 @@ __device__ __forceinline__ void trav_set_ray(Trav& t, const d3 o, const d3 d) {
   t.my_hi = -(oy + pad) * t.iy;
   t.mz_lo = -(oz - pad) * t.iz;
   t.mz_hi = -(oz + pad) * t.iz;
+  if (QUANT) {
+    // plane = lo + q * step, so t = q * (step * inv) + (lo * inv - (o -+ pad) * inv). The three
+    // extra roundings each move a plane distance by at most 2^-24 of (scene extent * |inv|); the
+    // grid planes lie a whole grid step (2^-16 of the extent) outside the binary32 planes.
+    t.mx_lo += sc.q_lo[0] * t.ix;
+    t.mx_hi += sc.q_lo[0] * t.ix;
+    t.my_lo += sc.q_lo[1] * t.iy;
+    t.my_hi += sc.q_lo[1] * t.iy;
+    t.mz_lo += sc.q_lo[2] * t.iz;
+    t.mz_hi += sc.q_lo[2] * t.iz;
+    t.ix *= sc.q_step[0];
+    t.iy *= sc.q_step[1];
+    t.iz *= sc.q_step[2];
+  }
 }
 
+template <bool QUANT = false>
 __device__ __forceinline__ void trav_begin(Trav& t, const SceneK& sc, const d3 o, const d3 d, int32_t* stk) {
-  trav_set_ray(t, o, d);
+  trav_set_ray<QUANT>(t, sc, o, d);
   t.best32k = __int_as_float(0x7f800000);
   t.best_t = __longlong_as_double(0x7ff0000000000000ll);
   t.best_u = 0.0;
@@ -284,7 +302,7 @@ __device__ __forceinline__ void trav_begin(Trav& t, const SceneK& sc, const d3 o
 }
 
 // Runs the traversal to its end (t.cur == RT_REF_SENTINEL).
-template <bool COUNT>
+template <bool COUNT, bool QUANT = false>
 __device__ __forceinline__ void trav_run(Trav& t, const SceneK& sc, const int stride, WorkCount& wc) {
   const double eps = 0.00000001;  // src/main.rs:185
   const d3 o = t.o, d = t.d;
@@ -301,9 +319,22 @@ __device__ __forceinline__ void trav_run(Trav& t, const SceneK& sc, const int st
     RT_ACC(wc, 5);
     while (cur >= 0) {
       steps += 1;
-      const float4* np = reinterpret_cast<const float4*>(sc.nodes + cur);
-      const float4 bx = np[0], by = np[1], bz = np[2];
-      const int4 ch = reinterpret_cast<const int4*>(np)[3];
+      float4 bx, by, bz;
+      int4 ch;
+      if (QUANT) {
+        const uint4* np = reinterpret_cast<const uint4*>(sc.qnodes + cur);
+        const uint4 w0 = np[0], w1 = np[1];
+        bx = make_float4((float)(w0.x & 0xffffu), (float)(w0.x >> 16), (float)(w0.y & 0xffffu), (float)(w0.y >> 16));
+        by = make_float4((float)(w0.z & 0xffffu), (float)(w0.z >> 16), (float)(w0.w & 0xffffu), (float)(w0.w >> 16));
+        bz = make_float4((float)(w1.x & 0xffffu), (float)(w1.x >> 16), (float)(w1.y & 0xffffu), (float)(w1.y >> 16));
+        ch = make_int4((int)w1.z, (int)w1.w, 0, 0);
+      } else {
+        const float4* np = reinterpret_cast<const float4*>(sc.nodes + cur);
+        bx = np[0];
+        by = np[1];
+        bz = np[2];
+        ch = reinterpret_cast<const int4*>(np)[3];
+      }
       if (COUNT) {
         wc.nodes++;
         if (first_active_lane()) wc.wi_inner++;

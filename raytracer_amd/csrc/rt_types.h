@@ -36,6 +36,16 @@ struct alignas(16) BvhNode {
   int32_t pad[2];
 };
 
+// The same node in half the bytes, for the launches over the ray queue: their rays are incoherent,
+// every lane of a wave fetches a different node, and what limits them is the number of load
+// instructions the texture addressers process, not arithmetic. The twelve planes are 16-bit
+// positions on a uniform grid over the scene's bounds (per axis: lo + q * step), rounded outward by
+// at least one grid step beyond the binary32 planes of BvhNode, so the boxes only grow.
+struct alignas(16) BvhNodeQ {
+  uint16_t q[12];  // x: child0.min child0.max child1.min child1.max, then y, then z
+  int32_t child[2];
+};
+
 struct alignas(16) TriGeom {
   double a[3];
   double ab[3];  // b - a
@@ -79,6 +89,7 @@ static inline size_t rt_texel_offset(uint32_t x, uint32_t y, uint32_t blocks_x) 
 }
 
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+static_assert(sizeof(BvhNodeQ) == 32, "BvhNodeQ must be 32 bytes");
 static_assert(sizeof(TriGeom) == 80, "TriGeom must be 80 bytes");
 static_assert(sizeof(TriShade) == 128, "TriShade must be 128 bytes");
 static_assert(sizeof(SphereRec) == 48, "SphereRec must be 48 bytes");

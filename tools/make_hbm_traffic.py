@@ -2,10 +2,17 @@
 """profiles/hbm_traffic.json (what bench.py reads for roofline.traffic and roofline.valu_issue) from
 a PMC summary made by tools/pmc_summary.py:
 
-    python tools/make_hbm_traffic.py profiles/r01/g_pmc_summary.json sphere_floor_1080p_64spp
+    python tools/make_hbm_traffic.py profiles/r02/workloads/sphere_floor_1080p_64spp_pmc_summary.json sphere_floor_1080p_64spp [revision]
+
+The launches of one stage are one entry: the kernel's third template argument (the variant that
+loops over the blocks of work left over by a launch sized from the previous frame) is folded
+away, sums and launch counts added. `revision` (default: git's HEAD) is recorded as
+_library_revision, the source state the library that was profiled was built from.
 """
 import json
 import os
+import re
+import subprocess
 import sys
 
 src, workload = sys.argv[1], sys.argv[2]
@@ -14,16 +21,32 @@ dst = os.path.join(root, "profiles", "hbm_traffic.json")
 pmc = json.load(open(src))
 out = json.load(open(dst)) if os.path.exists(dst) else {}
 out["_doc"] = (
-    "Per kernel, means over every launch in rocprofv3 PMC passes of bench.py's default command (separate --pmc FETCH_SIZE, "
+    "Per workload (bench.py --workload) and kernel, means over every launch in rocprofv3 PMC passes of bench.py (separate --pmc FETCH_SIZE, "
     "--pmc WRITE_SIZE and SQ runs, profiles/run_profile.sh): bytes_per_launch = HBM bytes, FETCH_SIZE doubled for the gfx950 "
     "under-count of wide reads, both counters in KiB; valu_wave_insts_per_launch = SQ_INSTS_VALU; valu_lane_use = "
-    "SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU). Source: " + os.path.relpath(os.path.abspath(src), root) + "."
+    "SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU). Launches of one stage (k_wave<false,S,*>) are one entry. _sources names the "
+    "summary each workload was taken from, _library_revision the source state of the profiled library."
 )
-w = {}
+out.setdefault("_sources", {})[workload] = os.path.relpath(os.path.abspath(src), root)
+if len(sys.argv) > 3:
+    out["_library_revision"] = sys.argv[3]
+else:
+    out["_library_revision"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=root, capture_output=True, text=True).stdout.strip()
+need = ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU")
+merged = {}
 for name, c in pmc.items():
-    if not name.startswith("k_") or "<true" in name or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+    if not name.startswith("k_") or "<true" in name or any(k not in c for k in need):
         continue
-    w[name.replace(", ", ",")] = {
+    key = re.sub(r"^(k_wave<false,\d+),(?:false|true)>", r"\1>", name.replace(", ", ","))
+    m = merged.setdefault(key, {k: {"launches": 0, "sum": 0.0} for k in need})
+    for k in need:
+        m[k]["launches"] += c[k]["launches"]
+        m[k]["sum"] += c[k]["sum"]
+w = {}
+for key, c in merged.items():
+    for k in need:
+        c[k]["per_launch"] = c[k]["sum"] / max(1, c[k]["launches"])
+    w[key] = {
         "launches_profiled": c["FETCH_SIZE"]["launches"],
         "fetch_kib_per_launch": c["FETCH_SIZE"]["per_launch"],
         "write_kib_per_launch": c["WRITE_SIZE"]["per_launch"],

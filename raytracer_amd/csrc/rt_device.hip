@@ -45,6 +45,7 @@ using namespace rtk;
 #ifndef RT_GRID_NODES
 #define RT_GRID_NODES 1
 #endif
+#define RT_LEAVE_DEFAULT 32      /* of 64: share of a wave's traversing lanes below which node steps pause for the leaves (trav_run) */
 #define RT_LONG_STEPS_DEFAULT 8u /* node visits from which a ray counts as long (see k_wave) */
 // words of a line
 enum { CNT_RAYS = 0, CNT_NODES, CNT_TRIS, CNT_SPHERES, CNT_SHADED, CNT_PATHS, CNT_Q0, CNT_R0, CNT_Q1, CNT_R1, CNT_WORK, CNT_WI_INNER, CNT_WI_LEAF, CNT_WI_REJECT, CNT_WAVES, CNT_N };
@@ -368,6 +369,10 @@ int rt_device_scene_upload_from(const rt_scene* s, rt_scene* target, int device)
   d->k.root_ref = s->root_ref;
   d->k.n_spheres = (uint32_t)s->spheres.size();
   d->k.has_emission = 0;
+  {
+    const char* e = std::getenv("RT_LEAVE");
+    d->k.leave_q = e && *e ? std::max(0, std::min(64, std::atoi(e))) : RT_LEAVE_DEFAULT;
+  }
   for (const rt_material& m : s->materials)
     if (m.emission[0] != 0.0 || m.emission[1] != 0.0 || m.emission[2] != 0.0) d->k.has_emission = 1;
   d->stack_entries = s->bvh_depth + 2;

@@ -163,6 +163,7 @@ struct SceneK {
   int32_t root_ref;
   uint32_t n_spheres;
   uint32_t has_emission;  // some material has a non-zero emission
+  int32_t leave_q;        // traversal: see trav_run
 };
 
 struct HitK {
@@ -317,7 +318,13 @@ __device__ __forceinline__ void trav_run(Trav& t, const SceneK& sc, const int st
 
   while (cur != RT_REF_SENTINEL) {
     RT_ACC(wc, 5);
+    // The lanes that have reached a leaf wait for the others to reach theirs, but not for a few
+    // stragglers: once fewer than leave_q / 64 of the lanes still traversing are stepping through
+    // nodes, those pause (cur stays >= 0) while the leaves found so far are tested. Only the
+    // interleaving of the lanes changes, not what any ray visits.
+    const int leave_at = (__popcll(__ballot(1)) * sc.leave_q) >> 6;  // the lanes inside this loop vote
     while (cur >= 0) {
+      if (__popcll(__ballot(1)) < leave_at) break;
       steps += 1;
       float4 bx, by, bz;
       int4 ch;
@@ -383,6 +390,7 @@ __device__ __forceinline__ void trav_run(Trav& t, const SceneK& sc, const int st
     }
     RT_ACC(wc, 4);
     if (cur == RT_REF_SENTINEL) break;
+    if (cur >= 0) continue;  // paused on the way to its next leaf
     // leaf
     const uint32_t leaf = (uint32_t)~cur;
     const uint32_t first = leaf >> RT_LEAF_BITS, cnt = (leaf & (uint32_t)(RT_LEAF_MAX - 1)) + 1u;

@@ -32,7 +32,7 @@ if a.device_build:
 s.upload(0)
 print(f"tree: {s.info().bvh_nodes} nodes, {s.info().bvh_leaves} leaves, depth {s.info().bvh_depth}")
 canvas = torch.zeros((a.height, a.width, 3), dtype=torch.float64, device="cuda")
-KIND = {0: "first", 1: "bounce", 2: "tail", 3: "single", 4: "resolve"}
+KIND = {0: "first", 1: "bounce", 2: "tail", 3: "single", 4: "resolve", 5: "shade", 6: "extend"}
 FORMS = {"wave": 0, "mega": _ffi.RT_FLAG_MEGAKERNEL, "noregen": _ffi.RT_FLAG_NO_REGEN}
 for form in a.forms.split(","):
     flags = FORMS[form] | _ffi.RT_FLAG_TIMING | (_ffi.RT_FLAG_COUNT_WORK if a.count else 0)
@@ -47,5 +47,6 @@ for form in a.forms.split(","):
     print(f"== {form}: wall {wall:.2f} ms, kernels {tm.ms_paths:.2f} + resolve {tm.ms_resolve:.2f} ms, {rays} rays, {rays / wall / 1e3:.0f} Mrays/s, {len(log)} launches")
     for l in log[:14]:
         extra = (f" nodes/ray {l.node_visits / max(1, l.rays):.2f} tris/ray {l.tri_tests / max(1, l.rays):.2f} | per wave: inner {l.wave_iters_inner / max(1, l.waves):.1f}"
-                 f" leaf {l.wave_iters_leaf / max(1, l.waves):.1f} reject {l.wave_iters_reject / max(1, l.waves):.1f}") if a.count else ""
+                 f" leaf {l.wave_iters_leaf / max(1, l.waves):.1f} reject {l.wave_iters_reject / max(1, l.waves):.1f}"
+                 f" | lanes busy: node steps {l.node_visits / max(1, 64 * l.wave_iters_inner):.2f} triangle tests {l.tri_tests / max(1, 64 * l.wave_iters_leaf):.2f}") if a.count else ""
         print(f"   {KIND[l.kind]:8s} items {l.items:>10d} rays {l.rays:>10d} {l.ms:8.3f} ms  {l.rays / max(l.ms, 1e-6) / 1e3:8.0f} Mrays/s{extra}")

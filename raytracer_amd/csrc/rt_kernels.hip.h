@@ -329,14 +329,15 @@ __device__ __forceinline__ void trav_run(Trav& t, const SceneK& sc, const int st
       float4 bx, by, bz;
       int4 ch;
       if (QUANT) {
-        const uint4* np = reinterpret_cast<const uint4*>(sc.qnodes + cur);
+        // a 32-bit byte offset from the (uniform) base: one shift per lane instead of 64-bit address arithmetic
+        const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.qnodes) + ((uint32_t)cur << 5));
         const uint4 w0 = np[0], w1 = np[1];
         bx = make_float4((float)(w0.x & 0xffffu), (float)(w0.x >> 16), (float)(w0.y & 0xffffu), (float)(w0.y >> 16));
         by = make_float4((float)(w0.z & 0xffffu), (float)(w0.z >> 16), (float)(w0.w & 0xffffu), (float)(w0.w >> 16));
         bz = make_float4((float)(w1.x & 0xffffu), (float)(w1.x >> 16), (float)(w1.y & 0xffffu), (float)(w1.y >> 16));
         ch = make_int4((int)w1.z, (int)w1.w, 0, 0);
       } else {
-        const float4* np = reinterpret_cast<const float4*>(sc.nodes + cur);
+        const float4* np = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sc.nodes) + ((uint32_t)cur << 6));
         bx = np[0];
         by = np[1];
         bz = np[2];
@@ -396,7 +397,7 @@ __device__ __forceinline__ void trav_run(Trav& t, const SceneK& sc, const int st
     const uint32_t first = leaf >> RT_LEAF_BITS, cnt = (leaf & (uint32_t)(RT_LEAF_MAX - 1)) + 1u;
     for (uint32_t i = 0; i < cnt; ++i) {
       if (COUNT && first_active_lane()) wc.wi_leaf++;
-      const TriGeom* g = sc.geom + (first + i);
+      const TriGeom* g = reinterpret_cast<const TriGeom*>(reinterpret_cast<const char*>(sc.geom) + (first + i) * (uint32_t)sizeof(TriGeom));
       const d3 a = mk(g->a[0], g->a[1], g->a[2]);
       const d3 a_to_b = mk(g->ab[0], g->ab[1], g->ab[2]);
       const d3 a_to_c = mk(g->ac[0], g->ac[1], g->ac[2]);

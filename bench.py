@@ -273,7 +273,8 @@ def main():
         # Roofline of the dominant kernel (largest total time in the timed region), against three
         # candidate bounds; the headline fraction is the largest of them, i.e. the bound the kernel
         # is closest to. Algorithmic work per ray, with that kernel's own per-ray means from the
-        # counting build: bytes = 64 B per interior node visited + 192 B per triangle tested (72 B
+        # counting build: bytes = 64 B per interior node visited (32 B in the launches over the queue,
+        # which walk the half-size copy of the tree) + 192 B per triangle tested (72 B
         # vertices + 72 B vertex normals + 48 B texture coordinates) + 48 B ray in + 40 B hit out;
         # flops = 24 per node visit (binary32 slab tests of two boxes) + 52 per triangle test + 30
         # per sphere test (binary64).
@@ -286,7 +287,9 @@ def main():
             c_rays, c_nodes, c_tris = cst.rays, cst.node_visits, cst.tri_tests
         if d_rays == 0:
             d_rays = rays_total
-        bytes_per_ray = 64.0 * c_nodes / c_rays + 192.0 * c_tris / c_rays + 88.0
+        # the launches over the queue (and the tail) walk the 32-byte copy of the nodes
+        node_bytes = 32.0 if dom in (1, 2) else 64.0
+        bytes_per_ray = node_bytes * c_nodes / c_rays + 192.0 * c_tris / c_rays + 88.0
         f32_flops_per_ray = 24.0 * c_nodes / c_rays
         f64_flops_per_ray = 52.0 * c_tris / c_rays + 30.0 * per_ray["spheres"]
         flops_per_ray = f32_flops_per_ray + f64_flops_per_ray

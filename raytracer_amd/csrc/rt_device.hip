@@ -1157,9 +1157,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
   for (;;) {
     if (alive) {
       Trav t;
-      // the launches over the queue walk the half-size copy of the tree (see BvhNodeQ)
-      trav_begin<STAGE != 0 && RT_GRID_NODES>(t, sc, o, dir, stk);
-      trav_run<COUNT, STAGE != 0 && RT_GRID_NODES>(t, sc, stride, wc);
+      // The launches over the queue walk the half-size copy of the tree (see BvhNodeQ): they are
+      // bound by node-fetch instructions. The tail is a few waves' serial chain, bound by latency:
+      // there the binary32 nodes (no conversions between the fetch and the tests) are quicker.
+      trav_begin<STAGE == 1 && RT_GRID_NODES>(t, sc, o, dir, stk);
+      trav_run<COUNT, STAGE == 1 && RT_GRID_NODES>(t, sc, stride, wc);
       steps = t.steps;
       wc.rays++;
       finish_hit<COUNT>(sc, o, dir, t.best_t, t.best_u, t.best_v, t.best_slot, h, wc);

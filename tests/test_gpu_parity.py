@@ -228,6 +228,16 @@ def test_render_variants_are_bitwise_identical(gpu_scenes, monkeypatch):
                 assert sum(l.rays for l in s2.last_launches()) == rays, env
         for k in env:
             monkeypatch.delenv(k)
+    # RT_LEAVE (read when a scene is uploaded): when a wave's node steps pause for its triangle
+    # tests changes how the lanes interleave, not what a ray visits
+    for leave in ("0", "8", "48", "64"):
+        monkeypatch.setenv("RT_LEAVE", leave)
+        s3 = scenes.build("spot")
+        c = np.zeros((h, w, 3))
+        assert s3.render(c, rt.render_params(width=w, height=h, spp=spp, seed=5, flags=_ffi.RT_FLAG_COUNT_WORK)) == rays
+        assert c.tobytes() == base.tobytes(), leave
+        assert (s3.last_stats().node_visits, s3.last_stats().tri_tests) == (st.node_visits, st.tri_tests), leave
+        monkeypatch.delenv("RT_LEAVE")
 
 
 def test_emissive_materials(oracle):

@@ -1494,7 +1494,6 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
   const bool count = (p->flags & RT_FLAG_COUNT_WORK) != 0;
   const bool regen = (p->flags & RT_FLAG_NO_REGEN) == 0;
   const bool emission = d->k.has_emission != 0;
-  const bool timing_or_count = timing || count;
 
   // Work buffers are bounded (RT_WORK_BUFFER_MIB); a call that needs more runs in sample chunks.
   const uint64_t n_pix = (uint64_t)tm.n_tiles * 64u;
@@ -1596,8 +1595,8 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
   const char* long_env = std::getenv("RT_LONG_STEPS");
   uint32_t long_steps = long_env && *long_env ? (uint32_t)std::max(0, std::atoi(long_env)) : RT_LONG_STEPS_DEFAULT;
   if (long_steps == 0) long_steps = 0x7fffffffu;
-  // RT_GRID_BLOCKS: workgroups of a launch over a queue (they loop over the queue's record blocks)
-  const uint32_t grid_blocks = (uint32_t)env_mib("RT_GRID_BLOCKS", 32768);
+  // RT_GRID_BLOCKS: workgroups of the looping form of a launch over a queue
+  const uint32_t grid_blocks = (uint32_t)env_mib("RT_GRID_BLOCKS", 4096);
   // RT_SYNC_ROUNDS=1: the host watches the queue counts of every frame (as on a frame of a new shape)
   const char* sync_env = std::getenv("RT_SYNC_ROUNDS");
   const bool always_watch = sync_env && *sync_env && *sync_env != '0';
@@ -1702,11 +1701,9 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
         qv[q] = QueueView{(float4*)queue[q], n_seg * seg_cap, queue_rad[q], seg_cap, (uint32_t)(q ? CNT_Q1 : CNT_Q0), (uint32_t)(q ? CNT_R1 : CNT_R0)};
       const size_t line_bytes = RT_LINE_WORDS * sizeof(unsigned long long);
       // grid of the looping form of the launches over a queue (it covers whatever the sized grid of
-      // the plain form did not): a few workgroups per segment
+      // the plain form did not, normally nothing): a few workgroups per segment
       const uint32_t seg_blocks = seg_cap / RT_BLOCK;
-      const dim3 qgrid(n_seg, std::max<uint32_t>(1u, std::min<uint32_t>(seg_blocks, (grid_blocks + n_seg - 1) / n_seg)));
-      // the same for launches that normally find nothing to do (behind a grid sized from experience)
-      const dim3 cgrid(n_seg, std::max<uint32_t>(1u, std::min<uint32_t>(seg_blocks, (4096u + n_seg - 1) / n_seg)));
+      const dim3 cgrid(n_seg, std::max<uint32_t>(1u, std::min<uint32_t>(seg_blocks, (grid_blocks + n_seg - 1) / n_seg)));
       // the four counts of every line start at zero (adjacent words)
       HIP_TRY(hipMemset2DAsync(counters + CNT_Q0, line_bytes, 0, 4 * sizeof(unsigned long long), RT_SHARDS, stream));
       if ((rc = begin_launch(0, pp.n_paths, stream)) != RT_OK) return rc;

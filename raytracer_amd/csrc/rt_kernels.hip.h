@@ -324,7 +324,7 @@ __device__ __forceinline__ void trav_run(Trav& t, const SceneK& sc, const int st
     // interleaving of the lanes changes, not what any ray visits.
     const int leave_at = (__popcll(__ballot(1)) * sc.leave_q) >> 6;  // the lanes inside this loop vote
     while (cur >= 0) {
-      if (__popcll(__ballot(1)) < leave_at) break;
+      if ((int)__popcll(__ballot(1)) < leave_at) break;
       steps += 1;
       float4 bx, by, bz;
       int4 ch;

@@ -308,6 +308,7 @@ def main():
         traffic = None
         valu_issue = None
         counters_note = "none for this workload"
+        library_digest = (_ffi.lib.rt_source_digest() or b"unknown").decode()  # digest of the sources the library was built from
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tfile):
             try:
@@ -315,7 +316,9 @@ def main():
                 pmc = tj.get(args.workload, {}).get(names[dom].split(" ")[0], {})
                 traffic = pmc.get("bytes_per_launch")
                 if traffic is not None:
-                    counters_note = f"replayed from profiles/hbm_traffic.json @{tj.get('_library_revision', 'unstamped')}"
+                    taken_on = tj.get("_library_digests", {}).get(args.workload, "unstamped")
+                    counters_note = (f"replayed from profiles/hbm_traffic.json, taken on library {taken_on} (git {tj.get('_library_revision', '?')}): "
+                                     + ("the library at hand" if taken_on == library_digest else f"STALE, the library at hand is {library_digest}"))
                 if pmc.get("valu_wave_insts_per_launch"):
                     prop = torch.cuda.get_device_properties(device)
                     simds = 4 * prop.multi_processor_count
@@ -407,6 +410,7 @@ def main():
             "per_ray": {k: round(v, 3) for k, v in per_ray.items()},
             "kernels": kernels,
             "roofline": roofline,
+            "library": library_digest,
             "ranks_seen": ranks_seen,
         }
         if secondary is not None:

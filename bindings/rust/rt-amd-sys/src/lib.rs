@@ -228,4 +228,5 @@ extern "C" {
     pub fn rt_quantize_rgba8(canvas: *const f64, width: u32, height: u32, its: u32, out: *mut u8) -> c_int;
     pub fn rt_selftest_division(n: u64, seed: u64, mismatches: *mut u64) -> c_int;
     pub fn rt_last_error() -> *const c_char;
+    pub fn rt_source_digest() -> *const c_char;
 }

@@ -437,6 +437,12 @@ int rt_selftest_division(uint64_t n, uint64_t seed, uint64_t* mismatches);
 
 const char* rt_last_error(void);
 
+/* No counterpart in the reference. Twelve hex digits: a digest of the source files this library
+ * was built from (made by the build, raytracer_amd/csrc/Makefile), "unknown" for a build that did
+ * not pass it. Measurements record it, so that counters replayed from a file can be told from
+ * counters of the library at hand. */
+const char* rt_source_digest(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -212,6 +212,7 @@ SIGNATURES = {
     "rt_quantize_rgba8": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32, _P]),
     "rt_selftest_division": (C.c_int, [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     "rt_last_error": (C.c_char_p, []),
+    "rt_source_digest": (C.c_char_p, []),
 }
 
 

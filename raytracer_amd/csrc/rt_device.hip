@@ -8,6 +8,8 @@
 //                  wavefront form: one launch per bounce over a compacted queue of live paths
 //   k_paths        the same loop as ONE kernel (per-lane bounce loop, optionally with lanes that
 //                  finish a path pulling the next one from a work counter) — kept for A/B
+//   k_plan         one block behind every launch that fills a queue: the extent of the next launch,
+//                  written where that launch's kernels read it, and a snapshot of the work counters
 //   k_gather       compacts the last queued records so that the tail can run on a side stream
 //   k_resolve      the per-pixel sums of src/main.rs:1020-1037 in sample order
 //

@@ -38,6 +38,11 @@ void rt_set_error(const char* fmt, ...) {
 
 extern "C" const char* rt_last_error(void) { return g_last_error.c_str(); }
 
+#ifndef RT_SOURCE_DIGEST
+#define RT_SOURCE_DIGEST "unknown"
+#endif
+extern "C" const char* rt_source_digest(void) { return RT_SOURCE_DIGEST; }
+
 // ------------------------------------------------------------------------------------------
 // meshes — PolygonMesh, src/main.rs:566-574
 // ------------------------------------------------------------------------------------------

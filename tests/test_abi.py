@@ -39,4 +39,6 @@ def test_struct_sizes_match_header():
 
 def test_last_error_is_a_string():
     assert isinstance(_ffi.lib.rt_last_error(), bytes)
+    digest = _ffi.lib.rt_source_digest()
+    assert isinstance(digest, bytes) and len(digest) == 12 and int(digest, 16) >= 0  # the build passed it
     assert _ffi.lib.rt_device_count() >= 0

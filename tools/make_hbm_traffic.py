@@ -25,9 +25,11 @@ out["_doc"] = (
     "--pmc WRITE_SIZE and SQ runs, profiles/run_profile.sh): bytes_per_launch = HBM bytes, FETCH_SIZE doubled for the gfx950 "
     "under-count of wide reads, both counters in KiB; valu_wave_insts_per_launch = SQ_INSTS_VALU; valu_lane_use = "
     "SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU). Launches of one stage (k_wave<false,S,*>) are one entry. _sources names the "
-    "summary each workload was taken from, _library_revision the source state of the profiled library."
+    "summary each workload was taken from, _library_digests the source digest (rt_source_digest) of the library each was taken on, "
+    "_library_revision git's HEAD when this file was last written."
 )
 out.setdefault("_sources", {})[workload] = os.path.relpath(os.path.abspath(src), root)
+out.setdefault("_library_digests", {})[workload] = pmc.get("_library_digest", "unstamped")  # rt_source_digest() of the profiled library
 if len(sys.argv) > 3:
     out["_library_revision"] = sys.argv[3]
 else:

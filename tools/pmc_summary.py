@@ -37,9 +37,23 @@ for name, counters in out.items():
     if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
         counters["hbm_bytes_per_launch"] = int(1024 * (2.0 * counters["FETCH_SIZE"]["per_launch"] + counters["WRITE_SIZE"]["per_launch"]))
 keep = {k: v for k, v in out.items() if k.startswith("k_")}
+# the library the passes ran on: bench.py prints its source digest in its JSON line (the logs keep it)
+digests = set()
+for log in glob.glob(os.path.join(src, "*.log")):
+    for line in open(log, errors="replace"):
+        if line.startswith("{") and '"library"' in line:
+            try:
+                digests.add(json.loads(line)["library"])
+            except (ValueError, KeyError):
+                pass
+if digests:
+    keep["_library_digest"] = sorted(digests)[0] if len(digests) == 1 else "mixed: " + ", ".join(sorted(digests))
 json.dump(keep, open(prefix + "_pmc_summary.json", "w"), indent=1, sort_keys=True)
 for name in sorted(keep):
     print(name)
+    if not isinstance(keep[name], dict):
+        print("   ", keep[name])
+        continue
     for counter, c in sorted(keep[name].items()):
         if isinstance(c, dict):
             print(f"   {counter:26s} launches {c['launches']:4d}  per launch {c['per_launch']:.4g}")

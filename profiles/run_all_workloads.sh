@@ -2,8 +2,9 @@
 # The five profiling passes of profiles/run_profile.sh for a list of bench.py workloads, one after
 # the other. Usage (through gpurun, from the repo root):
 #   bash profiles/run_all_workloads.sh <tag> <workload> [<workload> ...]
-# Output: gpurun_out/prof_<tag>_<workload>/; reduce each with tools/pmc_summary.py, then
-# tools/make_hbm_traffic.py.
+# Output: gpurun_out/sum_<tag>/<workload>_{kernel_stats.csv,pmc_summary.json} (tools/pmc_summary.py,
+# run here) and the logs under gpurun_out/prof_<tag>_<workload>/; afterwards copy the summaries into
+# profiles/ and run tools/make_hbm_traffic.py on each.
 set -e
 TAG=$1; shift
 for w in "$@"; do
@@ -13,6 +14,9 @@ for w in "$@"; do
   esac
   echo "== $w"
   BENCH_ARGS="--workload $w $extra" bash profiles/run_profile.sh ${TAG}_$w > /dev/null
-  tail -c 300 gpurun_out/prof_${TAG}_$w/trace.log | tr '\n' ' ' | cut -c1-200
-  echo
+  # reduce here and drop the raw counter files: what a call may bring back is bounded
+  mkdir -p gpurun_out/sum_$TAG
+  python tools/pmc_summary.py gpurun_out/prof_${TAG}_$w gpurun_out/sum_$TAG/$w > /dev/null
+  find gpurun_out/prof_${TAG}_$w -name "*.csv" -delete
+  ls gpurun_out/sum_$TAG | grep -c $w
 done

@@ -21,7 +21,10 @@ if stats:
     shutil.copy(stats[0], prefix + "_kernel_stats.csv")
 
 out = {}
-for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+found = glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True)
+if not found:
+    sys.exit(f"{src}: no counter files (pmc_*/**/*counter_collection.csv): nothing written")
+for f in found:
     per_dispatch = {}
     for row in csv.DictReader(open(f)):
         name = row["Kernel_Name"].split("(")[0].replace("void ", "").strip()

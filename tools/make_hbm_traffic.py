@@ -5,8 +5,9 @@ a PMC summary made by tools/pmc_summary.py:
     python tools/make_hbm_traffic.py profiles/r02/workloads/sphere_floor_1080p_64spp_pmc_summary.json sphere_floor_1080p_64spp [revision]
 
 The launches of one stage are one entry: the kernel's third template argument (the variant that
-loops over the blocks of work left over by a launch sized from the previous frame) is folded
-away, sums and launch counts added. `revision` (default: git's HEAD) is recorded as
+loops over the blocks of work left over by a launch sized from the previous frame, queued behind
+the plain one as part of the same logged launch) is folded away — its counts are added, the
+number of launches is the plain variant's. `revision` (default: git's HEAD) is recorded as
 _library_revision, the source state the library that was profiled was built from.
 """
 import json
@@ -40,9 +41,13 @@ for name, c in pmc.items():
     if not name.startswith("k_") or "<true" in name or any(k not in c for k in need):
         continue
     key = re.sub(r"^(k_wave<false,\d+),(?:false|true)>", r"\1>", name.replace(", ", ","))
+    # the looping variant is queued behind the plain one as part of the same logged launch: its
+    # counts are added, the number of launches is the plain variant's
+    looping = name.replace(" ", "").endswith(",true>")
     m = merged.setdefault(key, {k: {"launches": 0, "sum": 0.0} for k in need})
     for k in need:
-        m[k]["launches"] += c[k]["launches"]
+        if not looping:
+            m[k]["launches"] += c[k]["launches"]
         m[k]["sum"] += c[k]["sum"]
 w = {}
 for key, c in merged.items():

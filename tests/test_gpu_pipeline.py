@@ -108,3 +108,35 @@ def test_stream_wait_orders_another_stream_behind_a_pipelined_frame(spot):
     assert spot.last_stats().rays > 0
     fresh = scenes.build("sphere_floor")
     fresh.stream_wait(0)  # nothing uploaded, nothing queued: returns at once
+
+
+@pytest.mark.parametrize("flags", [0, _ffi.RT_FLAG_PIPELINE])
+def test_frames_unlike_the_one_their_shape_was_learnt_on(monkeypatch, flags):
+    """The launches of a frame are sized from the first frame of its shape (size, spp, depth cap,
+    thresholds: not the camera). A later frame of that shape whose queues are several times longer,
+    or much shorter, than the learnt ones must still render every path: the looping launches cover
+    what the sized grids miss, and the tail takes whatever the learnt number of bounces left."""
+    monkeypatch.setenv("RT_TAIL_THRESHOLD", "200")
+    fovs = (150.0, 25.0, 60.0, 170.0, 8.0)  # mostly sky first, then mostly geometry, ...
+    params = [rt.render_params(width=W, height=H, spp=SPP, first_sample=i * SPP, seed=9, fov_y_deg=f, flags=flags) for i, f in enumerate(fovs)]
+    # reference: the host watches every frame's queue counts
+    monkeypatch.setenv("RT_SYNC_ROUNDS", "1")
+    ref = scenes.build("spot")
+    ref.upload(0)
+    want, rays = [], []
+    for p in params:
+        c = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")
+        ref.render_device(c.data_ptr(), p, torch.cuda.current_stream().cuda_stream)
+        ref.wait()
+        rays.append(ref.last_stats().rays)
+        want.append(c.cpu().numpy().tobytes())
+    assert max(rays) > 1.5 * min(rays)  # the frames do differ in work
+    monkeypatch.delenv("RT_SYNC_ROUNDS")
+    s = scenes.build("spot")
+    s.upload(0)
+    for p, w, r in zip(params, want, rays):
+        c = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")
+        s.render_device(c.data_ptr(), p, torch.cuda.current_stream().cuda_stream)
+        s.wait()
+        assert s.last_stats().rays == r
+        assert c.cpu().numpy().tobytes() == w

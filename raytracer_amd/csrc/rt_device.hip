@@ -1069,7 +1069,9 @@ __global__ __launch_bounds__(RT_PLAN_THREADS) void k_plan(unsigned long long* co
   }
 }
 
-// LOOP = false: workgroup (s, y) handles record block vb_base + y of segment s, or nothing if the
+// STAGE 0: LOOP = false follows exactly one bounce before it queues its hits (pp.fuse_bounces must
+// be 1), LOOP = true follows pp.fuse_bounces of them.
+// Later stages: LOOP = false: workgroup (s, y) handles record block vb_base + y of segment s, or nothing if the
 // plan says the segment has fewer. LOOP = true: it handles blocks vb_base + y, + gridDim.y, ... to
 // the end — the form that cannot fall short whatever the counts turn out to be; it holds more
 // registers, so the host launches the first form on a grid sized from experience and the second
@@ -1156,7 +1158,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
   h.slot = -1;
   h.sphere = -1;
   int32_t steps = 0;  // node visits of the ray that found this lane's hit
-  for (;;) {
+  auto trace = [&]() {
     if (alive) {
       Trav t;
       // The launches over the queue walk the half-size copy of the tree (see BvhNodeQ): they are
@@ -1175,21 +1177,37 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
         n_done++;
       }
     }
-    // from here on `alive` means: has a hit waiting to be shaded
+  };
+  // from a trace on `alive` means: has a hit waiting to be shaded
+  auto shade = [&]() {
+    if (alive) {
+      if (COUNT) wc.shaded++;
+      const ShadeIn si = shade_input(h, o, dir);
+      shade_hit<COUNT>(sc, si, key, depth, o, dir, thr, rad, wc);
+      depth += 1;
+      if (depth > pp.max_depth) {
+        store_sample(samples, pp.n_paths, path, rad);
+        alive = false;
+        n_done++;
+      }
+    }
+  };
+  if (STAGE == 0 && !LOOP) {
+    // The first stage following exactly one bounce, written out: camera ray, shade, scattered ray.
+    // As a loop (below, for any other number of fused bounces) the same code holds 124 registers
+    // instead of 92, which costs the kernel a wave per SIMD.
+    trace();
+    if (__any(alive)) {
+      shade();
+      trace();
+    }
+  } else
+  for (;;) {
+    trace();
     if (STAGE == 2 || (STAGE == 0 && fuse_left > 0)) {
       if (!__any(alive)) break;
       if (STAGE == 0) fuse_left--;
-      if (alive) {
-        if (COUNT) wc.shaded++;
-        const ShadeIn si = shade_input(h, o, dir);
-        shade_hit<COUNT>(sc, si, key, depth, o, dir, thr, rad, wc);
-        depth += 1;
-        if (depth > pp.max_depth) {
-          store_sample(samples, pp.n_paths, path, rad);
-          alive = false;
-          n_done++;
-        }
-      }
+      shade();
       continue;
     }
     break;
@@ -1237,7 +1255,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
       }
     }
   }
-  if (!LOOP) break;
+  if (!LOOP || STAGE == 0) break;  // the first stage has one block of paths per workgroup
   }  // record blocks of this workgroup
   flush_counts(wc, counters, COUNT, n_done, n_vb);
 }
@@ -1428,12 +1446,12 @@ static uint64_t queue_entries(uint32_t n_paths) {
 template <int STAGE>
 static void launch_wave(bool count, bool loop, dim3 grid, size_t lds, hipStream_t st, const SceneK& k, const PathParams& pp, const QueueView& in,
                         const QueueView& out, uint32_t n_seg, const PlanRec* plan, uint32_t vb_base, double* samples, unsigned long long* counters) {
-  if (STAGE == 0 || !loop) {
+  if (!loop) {
     if (count) hipLaunchKernelGGL((k_wave<true, STAGE, false>), grid, dim3(RT_BLOCK), lds, st, k, pp, in, out, n_seg, plan, vb_base, samples, counters);
     else hipLaunchKernelGGL((k_wave<false, STAGE, false>), grid, dim3(RT_BLOCK), lds, st, k, pp, in, out, n_seg, plan, vb_base, samples, counters);
   } else {
-    if (count) hipLaunchKernelGGL((k_wave<true, STAGE == 0 ? 1 : STAGE, true>), grid, dim3(RT_BLOCK), lds, st, k, pp, in, out, n_seg, plan, vb_base, samples, counters);
-    else hipLaunchKernelGGL((k_wave<false, STAGE == 0 ? 1 : STAGE, true>), grid, dim3(RT_BLOCK), lds, st, k, pp, in, out, n_seg, plan, vb_base, samples, counters);
+    if (count) hipLaunchKernelGGL((k_wave<true, STAGE, true>), grid, dim3(RT_BLOCK), lds, st, k, pp, in, out, n_seg, plan, vb_base, samples, counters);
+    else hipLaunchKernelGGL((k_wave<false, STAGE, true>), grid, dim3(RT_BLOCK), lds, st, k, pp, in, out, n_seg, plan, vb_base, samples, counters);
   }
 }
 
@@ -1709,7 +1727,8 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
       // the four counts of every line start at zero (adjacent words)
       HIP_TRY(hipMemset2DAsync(counters + CNT_Q0, line_bytes, 0, 4 * sizeof(unsigned long long), RT_SHARDS, stream));
       if ((rc = begin_launch(0, pp.n_paths, stream)) != RT_OK) return rc;
-      launch_wave<0>(count, false, dim3(blocks_all), lds, stream, d->k, pp, qv[0], qv[0], n_seg, nullptr, 0u, samples, counters);
+      // the written-out form for one fused bounce (the default), the looping form for any other number
+      launch_wave<0>(count, fuse_bounces != 1u, dim3(blocks_all), lds, stream, d->k, pp, qv[0], qv[0], n_seg, nullptr, 0u, samples, counters);
       if ((rc = end_launch(stream)) != RT_OK) return rc;
       // the split of the plan (gather into the tail segment, or tail in place) only matters to the
       // launches after the last bounce, and costs nothing on the others

@@ -972,7 +972,7 @@ __device__ __forceinline__ uint32_t wave_reserve(unsigned long long* word, unsig
 // The same block leaves a snapshot of the cumulative work counters in host-visible memory, from
 // which the per-launch log is made once the frame is done.
 
-// One block, every thread on a few of the RT_SHARDS counter lines. plan[0] = extent of the queue whose
+// One block over the RT_SHARDS counter lines. plan[0] = extent of the queue whose
 // counts are words in_hit_word / in_ray_word of the first n_seg lines; with split_at > 0 also
 // plan[1] = plan[0] if the queue holds at most split_at records, else empty, and plan[2] the other
 // way round. zero_word >= 0: words zero_word, zero_word + 1 of every line are set to zero (the
@@ -981,76 +981,73 @@ __device__ __forceinline__ uint32_t wave_reserve(unsigned long long* word, unsig
 __global__ __launch_bounds__(RT_PLAN_THREADS) void k_plan(unsigned long long* counters, uint32_t in_hit_word, uint32_t in_ray_word, int zero_word,
                                                           uint32_t n_seg, uint32_t seg_cap, uint32_t split_at, PlanRec* __restrict__ plan,
                                                           LogRec* __restrict__ log) {
-  constexpr int WAVES = RT_PLAN_THREADS / 64, PER = RT_SHARDS / RT_PLAN_THREADS;  // lines t, t + 256, ... per thread
-  __shared__ unsigned long long s_sum[WAVES][CNT_N + 2];
-  __shared__ uint32_t s_max[WAVES][3];
+  // Thread t reads words 2p, 2p + 1 (p = t % 8) of lines t / 8, t / 8 + 32, ...: eight threads share
+  // a line, every load instruction of a wave covers eight whole lines, the 32 loads of a thread do
+  // not depend on each other, and the two counts of a queue (adjacent words, the first one even)
+  // meet in one thread.
+  static_assert(RT_LINE_WORDS == 16 && RT_SHARDS % (RT_PLAN_THREADS / 8) == 0, "k_plan's mapping of threads to words");
+  static_assert(CNT_Q0 % 2 == 0 && CNT_R0 == CNT_Q0 + 1 && CNT_Q1 % 2 == 0 && CNT_R1 == CNT_Q1 + 1, "queue counts are even-aligned pairs");
+  constexpr int WAVES = RT_PLAN_THREADS / 64, ROWS = RT_PLAN_THREADS / 8;
+  __shared__ unsigned long long s_sum[WAVES][RT_LINE_WORDS];
+  __shared__ uint32_t s_max[WAVES][RT_LINE_WORDS];
+  __shared__ uint32_t s_over[WAVES];
   const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63u;
-  unsigned long long nh_sum = 0, nr_sum = 0;
-  uint32_t mh = 0, mr = 0, ov = 0;
-#pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    const uint32_t seg = t + (uint32_t)k * RT_PLAN_THREADS;
-    if (seg < n_seg) {
-      const unsigned long long* line = counters + (size_t)seg * RT_LINE_WORDS;
-      const uint32_t nh = (uint32_t)line[in_hit_word], nr = (uint32_t)line[in_ray_word];
-      nh_sum += nh;
-      nr_sum += nr;
-      mh = max(mh, nh);
-      mr = max(mr, nr);
-      ov |= (uint64_t)nh + nr > seg_cap ? 1u : 0u;
+  const uint32_t word = 2u * (t & 7u), row0 = t >> 3;
+  const bool zero_it = zero_word >= 0 && word == (uint32_t)zero_word;
+  const bool counts = word == in_hit_word;  // then word + 1 == in_ray_word
+  unsigned long long sum0 = 0ull, sum1 = 0ull;  // of this thread's words: over every line, or over the segments if they are the queue's counts
+  uint32_t mx0 = 0u, mx1 = 0u, ov = 0u;
+#pragma unroll 8
+  for (uint32_t k = 0; k < RT_SHARDS / ROWS; ++k) {
+    const uint32_t seg = row0 + k * ROWS;
+    ulonglong2* p = reinterpret_cast<ulonglong2*>(counters + (size_t)seg * RT_LINE_WORDS + word);
+    ulonglong2 v = *p;
+    if (zero_it) *p = make_ulonglong2(0ull, 0ull);  // each word is read by exactly one thread: nobody else still needs it
+    if (counts) {
+      if (seg >= n_seg) v = make_ulonglong2(0ull, 0ull);
+      mx0 = max(mx0, (uint32_t)v.x);
+      mx1 = max(mx1, (uint32_t)v.y);
+      ov |= (uint64_t)(uint32_t)v.x + (uint32_t)v.y > seg_cap ? 1u : 0u;
     }
+    sum0 += v.x;
+    sum1 += v.y;
   }
-  // sums of every word over the lines, and of the two counts over the segments: one word at a time
-#pragma unroll 1
-  for (int w = 0; w < CNT_N + 2; ++w) {
-    unsigned long long x = w == CNT_N ? nh_sum : nr_sum;
-    if (w < CNT_N) {
-      x = 0ull;
-#pragma unroll
-      for (int k = 0; k < PER; ++k) x += counters[(size_t)(t + (uint32_t)k * RT_PLAN_THREADS) * RT_LINE_WORDS + w];
-    }
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
-    if (lane == 0) s_sum[wave][w] = x;
+  // lanes l, l + 8, ..., l + 56 hold the same words
+  for (int off = 8; off < 64; off <<= 1) {
+    sum0 += __shfl_xor(sum0, off);
+    sum1 += __shfl_xor(sum1, off);
+    mx0 = max(mx0, (uint32_t)__shfl_xor((int)mx0, off));
+    mx1 = max(mx1, (uint32_t)__shfl_xor((int)mx1, off));
   }
-  for (int off = 32; off > 0; off >>= 1) {
-    mh = max(mh, (uint32_t)__shfl_down((int)mh, off));
-    mr = max(mr, (uint32_t)__shfl_down((int)mr, off));
-    ov |= (uint32_t)__shfl_down((int)ov, off);
+  for (int off = 32; off > 0; off >>= 1) ov |= (uint32_t)__shfl_xor((int)ov, off);
+  if (lane < 8u) {
+    s_sum[wave][word] = sum0;
+    s_sum[wave][word + 1u] = sum1;
+    s_max[wave][word] = mx0;
+    s_max[wave][word + 1u] = mx1;
   }
-  if (lane == 0) {
-    s_max[wave][0] = mh;
-    s_max[wave][1] = mr;
-    s_max[wave][2] = ov;
-  }
+  if (lane == 0) s_over[wave] = ov;
   __syncthreads();
-  if (zero_word >= 0) {
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      unsigned long long* line = counters + (size_t)(t + (uint32_t)k * RT_PLAN_THREADS) * RT_LINE_WORDS;
-      line[zero_word] = 0ull;
-      line[zero_word + 1] = 0ull;
-    }
-  }
-  // thread w adds up word w; thread 0 then has the two counts and the maxima to make the plan of
-  if (t < CNT_N + 2) {
+  if (t < RT_LINE_WORDS) {
     unsigned long long x = 0ull;
-    for (int k = 0; k < WAVES; ++k) x += s_sum[k][t];
+    uint32_t m = 0u;
+    for (int k = 0; k < WAVES; ++k) {
+      x += s_sum[k][t];
+      m = max(m, s_max[k][t]);
+    }
     s_sum[0][t] = x;
+    s_max[0][t] = m;
     if (log && t < CNT_N) log->w[t] = x;
   }
   __syncthreads();
   if (t == 0) {
-    uint32_t max_h = 0, max_r = 0, over = 0;
-    for (int k = 0; k < WAVES; ++k) {
-      max_h = max(max_h, s_max[k][0]);
-      max_r = max(max_r, s_max[k][1]);
-      over |= s_max[k][2];
-    }
+    uint32_t over = 0;
+    for (int k = 0; k < WAVES; ++k) over |= s_over[k];
     PlanRec pr;
-    pr.hit_blocks = (max_h + RT_BLOCK - 1) / RT_BLOCK;
-    pr.ray_blocks = (max_r + RT_BLOCK - 1) / RT_BLOCK;
-    pr.n_hit = (uint32_t)s_sum[0][CNT_N];
-    pr.n_ray = (uint32_t)s_sum[0][CNT_N + 1];
+    pr.hit_blocks = (s_max[0][in_hit_word] + RT_BLOCK - 1) / RT_BLOCK;
+    pr.ray_blocks = (s_max[0][in_ray_word] + RT_BLOCK - 1) / RT_BLOCK;
+    pr.n_hit = (uint32_t)s_sum[0][in_hit_word];
+    pr.n_ray = (uint32_t)s_sum[0][in_ray_word];
     const PlanRec none{0u, 0u, 0u, 0u};
     plan[0] = pr;
     if (split_at > 0) {

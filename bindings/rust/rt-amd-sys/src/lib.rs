@@ -203,6 +203,7 @@ extern "C" {
     pub fn rt_scene_export_objects(scene: *const rt_scene, object_kind: *mut i32, materials: *mut rt_material, spheres: *mut f64, sphere_obj: *mut i32) -> c_int;
     pub fn rt_scene_export_texture(scene: *const rt_scene, id: u32, width: *mut u32, height: *mut u32, rgba: *mut u8) -> c_int;
     pub fn rt_scene_export_bvh(scene: *const rt_scene, node_words: *mut u32, leaf_order: *mut i32) -> c_int;
+    pub fn rt_scene_export_grid_bvh(scene: *const rt_scene, node_words: *mut u32, lo_step: *mut f32, usable: *mut i32) -> c_int;
 
     pub fn rt_device_count() -> c_int;
     pub fn rt_scene_upload(scene: *mut rt_scene, device: c_int) -> c_int;

@@ -286,11 +286,21 @@ int rt_scene_export_texture(const rt_scene* scene, uint32_t id, uint32_t* width,
 /* Copies the acceleration structure out: nodes as bvh_nodes x 16 32-bit words (layout in
  * raytracer_amd/csrc/rt_types.h), and for each triangle slot in leaf order its flat index. */
 int rt_scene_export_bvh(const rt_scene* scene, uint32_t* node_words, int32_t* leaf_order);
+/* No counterpart in the reference. The launches over the ray queue walk a half-size copy of the
+ * tree whose planes are 16-bit positions on a grid over the scene's bounds; this copies it out:
+ * nodes as bvh_nodes x 8 32-bit words (twelve 16-bit planes: per axis child0.min, child0.max,
+ * child1.min, child1.max; then the two child refs), lo_step = {lo x, y, z, step x, y, z} with
+ * plane = lo + q * step. *usable = 0, and nothing is copied, for a scene that does not qualify
+ * (a coordinate beyond 2^20 grid steps, i.e. a scene some sixteen times its own size away from
+ * the origin, or a non-finite box): such a scene is walked through the binary32 nodes everywhere. */
+int rt_scene_export_grid_bvh(const rt_scene* scene, uint32_t* node_words, float* lo_step, int32_t* usable);
 
 /* ---- device side ------------------------------------------------------------------------ */
 
 int rt_device_count(void);
-/* Copies the scene into the HBM of `device` (idempotent for the same device). */
+/* Copies the scene into the HBM of `device` (idempotent for the same device). The kernels address
+ * nodes and triangles with 32-bit byte offsets: a scene of 2^32 / 80 (53 687 091) triangles or
+ * more, or of 2^26 interior nodes or more, is refused with RT_ERR_INVALID. */
 int rt_scene_upload(rt_scene* scene, int device);
 
 /* Replaces the scene's tree (built on the host when the scene was created; BVH::build,
@@ -344,7 +354,7 @@ int rt_render_device(rt_scene* scene, const rt_render_params* p, double* device_
 
 /* No counterpart in the reference. rt_render_device for callers that cannot allocate (code under
  * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): the sample buffer,
- * the running per-pixel totals, both ray queues and the counters come out of one static array in
+ * the running per-pixel totals and both ray queues come out of one static array in
  * device memory, RT_NOALLOC_SCRATCH_MIB MiB per GPU, held by every GPU the library runs on until
  * the process ends; the call makes no hipMalloc, hipFree, stream or event creation. The scene
  * must already be uploaded (rt_scene_upload allocates); RT_ERR_NO_DEVICE otherwise. The array

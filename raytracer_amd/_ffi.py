@@ -188,6 +188,7 @@ SIGNATURES = {
     "rt_scene_export_objects": (C.c_int, [_P, _P, _P, _P, _P]),
     "rt_scene_export_texture": (C.c_int, [_P, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _P]),
     "rt_scene_export_bvh": (C.c_int, [_P, _P, _P]),
+    "rt_scene_export_grid_bvh": (C.c_int, [_P, _P, _P, _P]),
     "rt_device_count": (C.c_int, []),
     "rt_scene_rebuild_on_device": (C.c_int, [_P, C.c_int]),
     "rt_scene_rebuild_on_device_with": (C.c_int, [_P, C.c_int, C.c_uint32]),

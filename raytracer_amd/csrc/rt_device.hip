@@ -30,6 +30,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -76,6 +77,7 @@ struct DeviceScene {
   std::vector<void*> allocs;
   uint64_t bytes = 0;
   uint32_t stack_entries = 2;
+  bool grid_ok = false;  // the launches over the queue walk qnodes (else nodes, like everything else)
   // work buffers, grown on demand
   double* samples = nullptr;
   size_t samples_bytes = 0;
@@ -158,8 +160,8 @@ struct DeviceScene {
 
 // ------------------------------------------------------------------------------------------
 // Static work memory for rt_render_device_noalloc: callers that may not allocate (code under
-// graph capture, serving loops, harnesses that forbid hipMalloc) get their sample buffer, ray
-// queues and counters out of this array instead of hipMalloc'ed buffers. Every GPU the library
+// graph capture, serving loops, harnesses that forbid hipMalloc) get their sample buffer and ray
+// queues out of this array instead of hipMalloc'ed buffers. Every GPU the library
 // runs on holds its own copy of the array, at its own address, until the process ends; the
 // array's name is only a host-side handle, so the address is asked for once per device and kept.
 // ------------------------------------------------------------------------------------------
@@ -167,6 +169,7 @@ struct DeviceScene {
 #define RT_SCRATCH_MAX_DEVICES 64
 static __device__ __align__(256) unsigned char scratch[RT_SCRATCH_BYTES];
 static unsigned char* g_scratch_ptr[RT_SCRATCH_MAX_DEVICES] = {};
+static std::mutex g_scratch_mutex;  // scenes may be uploaded from several host threads
 
 // Address of `device`'s copy of the array (the device is made current). Called when a scene is
 // uploaded, so that the render call itself finds the address already there.
@@ -175,6 +178,7 @@ static int scratch_address(int device, unsigned char** out) {
     rt_set_error("device %d is beyond the %d devices the static work memory is tracked for", device, RT_SCRATCH_MAX_DEVICES);
     return RT_ERR_INVALID;
   }
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
   if (!g_scratch_ptr[device]) {
     HIP_TRY(hipSetDevice(device));
     void* p = nullptr;
@@ -286,6 +290,13 @@ int rt_device_scene_upload_from(const rt_scene* s, rt_scene* target, int device)
     return RT_ERR_INVALID;
   }
   if (target->dev && target->dev->device == device) return RT_OK;
+  // trav_run addresses nodes and triangles with 32-bit byte offsets from the arrays' bases
+  if ((uint64_t)s->tri_geom.size() * sizeof(TriGeom) >= (1ull << 32) || (uint64_t)s->nodes.size() * sizeof(BvhNode) >= (1ull << 32)) {
+    rt_set_error("rt_scene_upload: %llu triangles / %llu nodes exceed what the kernels' 32-bit offsets address (%llu triangles, %llu nodes)",
+                 (unsigned long long)s->tri_geom.size(), (unsigned long long)s->nodes.size(), (unsigned long long)((1ull << 32) / sizeof(TriGeom)),
+                 (unsigned long long)((1ull << 32) / sizeof(BvhNode)));
+    return RT_ERR_INVALID;
+  }
   if (target->dev) {
     rt_device_scene_free(target->dev);
     target->dev = nullptr;
@@ -301,58 +312,12 @@ int rt_device_scene_upload_from(const rt_scene* s, rt_scene* target, int device)
   };
   if ((rc = upload_array(d, s->nodes.data(), s->nodes.size(), &d->k.nodes)) != RT_OK) return fail(rc);
   {
-    // The tree once more on a 16-bit grid over its own bounds (BvhNodeQ). A grid plane lies at
-    // least one whole step outside the binary32 plane it stands for (and never inside the grid's
-    // ends), which is thousands of times the rounding the traversal's arithmetic adds.
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (const BvhNode& n : s->nodes) {
-      const float* planes[3] = {n.bx, n.by, n.bz};
-      for (int a = 0; a < 3; ++a)
-        for (int k = 0; k < 4; ++k) {
-          const float v = planes[a][k];
-          if (!std::isfinite(v)) continue;
-          lo[a] = std::min(lo[a], v);
-          hi[a] = std::max(hi[a], v);
-        }
-    }
-    for (int a = 0; a < 3; ++a)
-      if (!(lo[a] <= hi[a])) lo[a] = hi[a] = 0.f;  // no finite plane on this axis (an empty tree)
-    std::vector<BvhNodeQ> qn(s->nodes.size());
-    for (int a = 0; a < 3; ++a) {
-      // grid: q = 1 .. 65534 span [lo, hi]; 0 and 65535 are the outward steps of the extremes
-      double step = ((double)hi[a] - (double)lo[a]) / 65533.0;
-      if (!(step > 0.0)) step = 1.0;
-      float stepf = (float)step;
-      while ((double)stepf * 65533.0 < (double)hi[a] - (double)lo[a]) stepf = std::nextafterf(stepf, INFINITY);
-      float lof = (float)((double)lo[a] - (double)stepf);
-      while ((double)lof + (double)stepf > (double)lo[a]) lof = std::nextafterf(lof, -INFINITY);
-      d->k.q_lo[a] = lof;
-      d->k.q_step[a] = stepf;
-      for (size_t i = 0; i < s->nodes.size(); ++i) {
-        const BvhNode& n = s->nodes[i];
-        const float* planes = a == 0 ? n.bx : a == 1 ? n.by : n.bz;
-        for (int k = 0; k < 4; ++k) {
-          const bool is_max = (k & 1) != 0;
-          const double v = planes[k];
-          long q;
-          if (!std::isfinite(v)) {
-            q = is_max ? 65535 : 0;  // not a finite plane: as far out as the grid goes (the box is then always entered)
-          } else if (is_max) {
-            q = (long)std::ceil((v - (double)lof) / (double)stepf) + 1;
-            while ((double)lof + (double)(q - 1) * (double)stepf < v) ++q;
-          } else {
-            q = (long)std::floor((v - (double)lof) / (double)stepf) - 1;
-            while ((double)lof + (double)(q + 1) * (double)stepf > v) --q;
-          }
-          qn[i].q[a * 4 + k] = (uint16_t)std::min(65535l, std::max(0l, q));
-        }
-      }
-    }
-    for (size_t i = 0; i < s->nodes.size(); ++i) {
-      qn[i].child[0] = s->nodes[i].child[0];
-      qn[i].child[1] = s->nodes[i].child[1];
-    }
-    if ((rc = upload_array(d, qn.data(), qn.size(), &d->k.qnodes)) != RT_OK) return fail(rc);
+    // The tree once more on a 16-bit grid over its own bounds (BvhNodeQ), if the scene qualifies.
+    std::vector<BvhNodeQ> qn;
+    d->grid_ok = RT_GRID_NODES && rt_quantize_tree(s, &qn, d->k.q_lo, d->k.q_step);
+    const char* no_grid = std::getenv("RT_NO_GRID");
+    if (no_grid && *no_grid && *no_grid != '0') d->grid_ok = false;
+    if (d->grid_ok && (rc = upload_array(d, qn.data(), qn.size(), &d->k.qnodes)) != RT_OK) return fail(rc);
   }
   if ((rc = upload_array(d, s->tri_geom.data(), s->tri_geom.size(), &d->k.geom)) != RT_OK) return fail(rc);
   if ((rc = upload_array(d, s->tri_shade.data(), s->tri_shade.size(), &d->k.shade)) != RT_OK) return fail(rc);
@@ -1073,7 +1038,7 @@ __global__ __launch_bounds__(RT_PLAN_THREADS) void k_plan(unsigned long long* co
 // the end — the form that cannot fall short whatever the counts turn out to be; it holds more
 // registers, so the host launches the first form on a grid sized from experience and the second
 // behind it for whatever that grid did not cover (normally nothing).
-template <bool COUNT, int STAGE, bool LOOP>
+template <bool COUNT, int STAGE, bool LOOP, bool QUANT>
 __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, QueueView in, QueueView out, uint32_t n_seg,
                                                    const PlanRec* __restrict__ plan, uint32_t vb_base, double* __restrict__ samples,
                                                    unsigned long long* counters) {
@@ -1161,8 +1126,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
       // The launches over the queue walk the half-size copy of the tree (see BvhNodeQ): they are
       // bound by node-fetch instructions. The tail is a few waves' serial chain, bound by latency:
       // there the binary32 nodes (no conversions between the fetch and the tests) are quicker.
-      trav_begin<STAGE == 1 && RT_GRID_NODES>(t, sc, o, dir, stk);
-      trav_run<COUNT, STAGE == 1 && RT_GRID_NODES>(t, sc, stride, wc);
+      trav_begin<QUANT>(t, sc, o, dir, stk);
+      trav_run<COUNT, QUANT>(t, sc, stride, wc);
       steps = t.steps;
       wc.rays++;
       finish_hit<COUNT>(sc, o, dir, t.best_t, t.best_u, t.best_v, t.best_slot, h, wc);
@@ -1440,16 +1405,34 @@ static uint64_t queue_entries(uint32_t n_paths) {
   return (uint64_t)n_seg * ((blocks + n_seg - 1) / n_seg) * RT_BLOCK;
 }
 
+// QUANT (the half-size grid nodes) exists for the launches over the queue only (STAGE 1).
+template <bool COUNT, int STAGE, bool LOOP, bool QUANT>
+static void launch_wave_as(dim3 grid, size_t lds, hipStream_t st, const SceneK& k, const PathParams& pp, const QueueView& in, const QueueView& out,
+                           uint32_t n_seg, const PlanRec* plan, uint32_t vb_base, double* samples, unsigned long long* counters) {
+  hipLaunchKernelGGL((k_wave<COUNT, STAGE, LOOP, QUANT>), grid, dim3(RT_BLOCK), lds, st, k, pp, in, out, n_seg, plan, vb_base, samples, counters);
+}
 template <int STAGE>
-static void launch_wave(bool count, bool loop, dim3 grid, size_t lds, hipStream_t st, const SceneK& k, const PathParams& pp, const QueueView& in,
+static void launch_wave(bool count, bool loop, bool quant, dim3 grid, size_t lds, hipStream_t st, const SceneK& k, const PathParams& pp, const QueueView& in,
                         const QueueView& out, uint32_t n_seg, const PlanRec* plan, uint32_t vb_base, double* samples, unsigned long long* counters) {
-  if (!loop) {
-    if (count) hipLaunchKernelGGL((k_wave<true, STAGE, false>), grid, dim3(RT_BLOCK), lds, st, k, pp, in, out, n_seg, plan, vb_base, samples, counters);
-    else hipLaunchKernelGGL((k_wave<false, STAGE, false>), grid, dim3(RT_BLOCK), lds, st, k, pp, in, out, n_seg, plan, vb_base, samples, counters);
+#define RT_LAUNCH_AS(C, L, Q) launch_wave_as<C, STAGE, L, Q>(grid, lds, st, k, pp, in, out, n_seg, plan, vb_base, samples, counters)
+  if (STAGE == 1 && quant) {
+    if (!loop) {
+      if (count) RT_LAUNCH_AS(true, false, (STAGE == 1));
+      else RT_LAUNCH_AS(false, false, (STAGE == 1));
+    } else {
+      if (count) RT_LAUNCH_AS(true, true, (STAGE == 1));
+      else RT_LAUNCH_AS(false, true, (STAGE == 1));
+    }
   } else {
-    if (count) hipLaunchKernelGGL((k_wave<true, STAGE, true>), grid, dim3(RT_BLOCK), lds, st, k, pp, in, out, n_seg, plan, vb_base, samples, counters);
-    else hipLaunchKernelGGL((k_wave<false, STAGE, true>), grid, dim3(RT_BLOCK), lds, st, k, pp, in, out, n_seg, plan, vb_base, samples, counters);
+    if (!loop) {
+      if (count) RT_LAUNCH_AS(true, false, false);
+      else RT_LAUNCH_AS(false, false, false);
+    } else {
+      if (count) RT_LAUNCH_AS(true, true, false);
+      else RT_LAUNCH_AS(false, true, false);
+    }
   }
+#undef RT_LAUNCH_AS
 }
 
 // `arena` != nullptr: the call takes every work buffer out of the arena (the static work memory)
@@ -1488,14 +1471,10 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
     d->n_events = 0;
     d->side_used = false;
     std::memset(&d->timing, 0, sizeof d->timing);
+    // Also for a call that takes its work buffers out of the static array: the counters are the
+    // scene's own (allocated at upload), so that the statistics read after the call cannot be
+    // overwritten by another scene's call on the same GPU.
     d->cur_counters = d->counters;
-    if (arena) {
-      d->cur_counters = static_cast<unsigned long long*>(arena_take(arena, RT_COUNTER_BYTES));
-      if (!d->cur_counters) {
-        rt_set_error("%s: the static work memory is smaller than the counters", who);
-        return RT_ERR_INVALID;
-      }
-    }
     HIP_TRY(hipMemsetAsync(d->cur_counters, 0, RT_COUNTER_BYTES, stream));
     HIP_TRY(hipMemsetAsync(d->tail_counters, 0, RT_COUNTER_BYTES, stream));
   }
@@ -1725,7 +1704,7 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
       HIP_TRY(hipMemset2DAsync(counters + CNT_Q0, line_bytes, 0, 4 * sizeof(unsigned long long), RT_SHARDS, stream));
       if ((rc = begin_launch(0, pp.n_paths, stream)) != RT_OK) return rc;
       // the written-out form for one fused bounce (the default), the looping form for any other number
-      launch_wave<0>(count, fuse_bounces != 1u, dim3(blocks_all), lds, stream, d->k, pp, qv[0], qv[0], n_seg, nullptr, 0u, samples, counters);
+      launch_wave<0>(count, fuse_bounces != 1u, false, dim3(blocks_all), lds, stream, d->k, pp, qv[0], qv[0], n_seg, nullptr, 0u, samples, counters);
       if ((rc = end_launch(stream)) != RT_OK) return rc;
       // the split of the plan (gather into the tail segment, or tail in place) only matters to the
       // launches after the last bounce, and costs nothing on the others
@@ -1774,8 +1753,8 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
         uint32_t gy = 0;
         const bool cover = sized_grid(rounds, snap, &gy);
         if ((rc = begin_launch(1, 0u, stream)) != RT_OK) return rc;
-        if (gy) launch_wave<1>(count, false, dim3(n_seg, gy), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, plan_at(snap), 0u, samples, counters);
-        if (cover) launch_wave<1>(count, true, cgrid, lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, plan_at(snap), gy, samples, counters);
+        if (gy) launch_wave<1>(count, false, d->grid_ok, dim3(n_seg, gy), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, plan_at(snap), 0u, samples, counters);
+        if (cover) launch_wave<1>(count, true, d->grid_ok, cgrid, lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, plan_at(snap), gy, samples, counters);
         if ((rc = end_launch(stream)) != RT_OK) return rc;
         const int64_t sized_by = snap;
         // counts of the queue just written; the counts of the one just read start the next round at zero
@@ -1796,7 +1775,7 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
         hipLaunchKernelGGL(k_gather, dim3(n_seg), dim3(RT_BLOCK), 0, stream, qv[cur], tv, (const PlanRec*)(plan_at(snap) + 1), (int)emission, counters, d->tail_counters);
         HIP_TRY(hipGetLastError());
         if ((rc = begin_launch(2, 0u, stream)) != RT_OK) return rc;
-        launch_wave<2>(count, true, cgrid, lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, plan_at(snap) + 2, 0u, samples, counters);
+        launch_wave<2>(count, true, false, cgrid, lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, plan_at(snap) + 2, 0u, samples, counters);
         if ((rc = end_launch(stream)) != RT_OK) return rc;
         {
           int64_t after;
@@ -1809,7 +1788,7 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
         int64_t tplan, tafter;
         if ((rc = take_plan(d->side, d->tail_counters, tv.hit_word, tv.ray_word, -1, 1u, tail_cap, 0u, &tplan)) != RT_OK) return rc;
         if ((rc = begin_launch(2, 0u, d->side)) != RT_OK) return rc;
-        launch_wave<2>(count, false, dim3(1, tail_cap / RT_BLOCK), lds, d->side, d->k, pp, tv, tv, 1u, plan_at(tplan), 0u, samples, d->tail_counters);
+        launch_wave<2>(count, false, false, dim3(1, tail_cap / RT_BLOCK), lds, d->side, d->k, pp, tv, tv, 1u, plan_at(tplan), 0u, samples, d->tail_counters);
         if ((rc = end_launch(d->side)) != RT_OK) return rc;
         if ((rc = take_plan(d->side, d->tail_counters, tv.hit_word, tv.ray_word, -1, 0u, 0u, 0u, &tafter)) != RT_OK) return rc;
         d->accounts.push_back(DeviceScene::Account{d->launches.size() - 1, tplan, tafter, tplan});
@@ -1821,8 +1800,8 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
         uint32_t gy = 0;
         const bool cover = sized_grid(rounds, snap, &gy);
         if ((rc = begin_launch(2, 0u, stream)) != RT_OK) return rc;
-        if (gy) launch_wave<2>(count, false, dim3(n_seg, gy), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, plan_at(snap), 0u, samples, counters);
-        if (cover) launch_wave<2>(count, true, cgrid, lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, plan_at(snap), gy, samples, counters);
+        if (gy) launch_wave<2>(count, false, false, dim3(n_seg, gy), lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, plan_at(snap), 0u, samples, counters);
+        if (cover) launch_wave<2>(count, true, false, cgrid, lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, plan_at(snap), gy, samples, counters);
         if ((rc = end_launch(stream)) != RT_OK) return rc;
         const int64_t sized_by = snap;
         if ((rc = take_plan(stream, counters, CNT_Q0, CNT_R0, -1, 0u, 0u, 0u, &snap)) != RT_OK) return rc;
@@ -1866,7 +1845,7 @@ static int rt_render_device_body(rt_scene* s, const rt_render_params* p, double*
 }
 
 // The same call as rt_render_device with every work buffer (sample buffer, running totals, both
-// ray queues, counters) taken out of the static work memory: no hipMalloc, hipFree, stream or
+// ray queues) taken out of the static work memory: no hipMalloc, hipFree, stream or
 // event creation. The scene must have been uploaded before (rt_scene_upload allocates).
 extern "C" int rt_render_device_noalloc(rt_scene* s, const rt_render_params* p, double* device_canvas, void* stream) {
   return rt_guard("rt_render_device_noalloc", [&] {

@@ -1067,6 +1067,107 @@ extern "C" int rt_scene_export_bvh(const rt_scene* s, uint32_t* node_words, int3
   return RT_OK;
 }
 
+// The tree once more on a 16-bit grid over its own bounds (BvhNodeQ): per axis a plane is
+// lo + q * step with q in 0..65535. Returns false, and the kernels then walk the binary32 nodes
+// everywhere, unless every grid box provably contains the binary32 box it stands for with a
+// margin that covers the traversal's own binary32 arithmetic:
+//   * a minimum plane lies at least one whole step below, a maximum plane at least one whole step
+//     above the binary32 plane (checked plane by plane, nothing is clamped into range);
+//   * the kernels form a plane distance as q * (step * inv) + (lo * inv - o * inv), four binary32
+//     roundings that each move the plane by at most 2^-24 of the scene's largest coordinate; the
+//     grid is only used when that coordinate is at most 2^20 steps (about sixteen times the
+//     scene's extent along the axis), which keeps their sum below a quarter of a step. A scene far
+//     from the origin relative to its size fails this and keeps its binary32 nodes.
+bool rt_quantize_tree(const rt_scene* s, std::vector<BvhNodeQ>* out, float q_lo[3], float q_step[3]) {
+  out->clear();
+  for (int a = 0; a < 3; ++a) {
+    q_lo[a] = 0.f;
+    q_step[a] = 1.f;
+  }
+  const size_t n = s->nodes.size();
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (const BvhNode& nd : s->nodes) {
+    const float* planes[3] = {nd.bx, nd.by, nd.bz};
+    for (int a = 0; a < 3; ++a)
+      for (int k = 0; k < 4; ++k) {
+        const float v = planes[a][k];
+        if (!std::isfinite(v)) return false;  // a box that reaches infinity has no place on a finite grid
+        lo[a] = std::min(lo[a], v);
+        hi[a] = std::max(hi[a], v);
+      }
+  }
+  out->resize(n);
+  for (int a = 0; a < 3; ++a) {
+    if (!(lo[a] <= hi[a])) lo[a] = hi[a] = 0.f;  // an empty tree
+    const double extent = (double)hi[a] - (double)lo[a];
+    // q = 1 .. 65533 span [lo, hi]; 0 is the outward step of the lowest plane, 65534 and 65535 those of the highest
+    double step = extent / 65532.0;
+    const double bound = std::max(std::fabs((double)lo[a]), std::fabs((double)hi[a]));
+    if (!(step > 0.0)) step = std::max(bound * 0x1p-18, 1e-30);  // a flat axis: any step the bound allows
+    float stepf = (float)step;
+    while ((double)stepf * 65532.0 < extent) stepf = std::nextafterf(stepf, INFINITY);
+    if (!std::isfinite(stepf) || !(stepf > 0.f) || (double)stepf < 1e-30) return false;
+    if (bound + (double)stepf > (double)stepf * 0x1p20) return false;
+    float lof = (float)((double)lo[a] - (double)stepf);
+    while ((double)lof + (double)stepf > (double)lo[a]) lof = std::nextafterf(lof, -INFINITY);
+    if (!std::isfinite(lof)) return false;
+    q_lo[a] = lof;
+    q_step[a] = stepf;
+    const double l = lof, st = stepf;
+    for (size_t i = 0; i < n; ++i) {
+      const BvhNode& nd = s->nodes[i];
+      const float* planes = a == 0 ? nd.bx : a == 1 ? nd.by : nd.bz;
+      for (int k = 0; k < 4; ++k) {
+        const bool is_max = (k & 1) != 0;
+        const double v = planes[k];
+        long q;
+        if (is_max) {
+          q = (long)std::ceil((v - l) / st) + 1;
+          while (l + (double)(q - 1) * st < v) ++q;
+        } else {
+          q = (long)std::floor((v - l) / st) - 1;
+          while (l + (double)(q + 1) * st > v) --q;
+        }
+        if (q < 0 || q > 65535) return false;
+        (*out)[i].q[a * 4 + k] = (uint16_t)q;
+      }
+    }
+  }
+  for (size_t i = 0; i < n; ++i) {
+    (*out)[i].child[0] = s->nodes[i].child[0];
+    (*out)[i].child[1] = s->nodes[i].child[1];
+  }
+  return true;
+}
+
+// Copies the 16-bit grid form of the tree out: nodes as bvh_nodes x 8 32-bit words (BvhNodeQ),
+// lo_step = the grid's {lo x, y, z, step x, y, z}; *usable = 0 (and nothing copied) when the scene
+// does not qualify for the grid and the kernels walk the binary32 nodes instead.
+extern "C" int rt_scene_export_grid_bvh(const rt_scene* s, uint32_t* node_words, float* lo_step, int32_t* usable) {
+  return rt_guard("rt_scene_export_grid_bvh", [&] {
+    if (!s || !usable) {
+      rt_set_error("rt_scene_export_grid_bvh: null argument");
+      return RT_ERR_INVALID;
+    }
+    if (!s->has_tree) {
+      rt_set_error("rt_scene_export_grid_bvh: the scene was created without a tree");
+      return RT_ERR_INVALID;
+    }
+    std::vector<BvhNodeQ> qn;
+    float lo[3], st[3];
+    *usable = rt_quantize_tree(s, &qn, lo, st) ? 1 : 0;
+    if (*usable) {
+      if (node_words && !qn.empty()) std::memcpy(node_words, qn.data(), qn.size() * sizeof(BvhNodeQ));
+      if (lo_step)
+        for (int a = 0; a < 3; ++a) {
+          lo_step[a] = lo[a];
+          lo_step[3 + a] = st[a];
+        }
+    }
+    return RT_OK;
+  });
+}
+
 extern "C" int rt_scene_export_objects(const rt_scene* s, int32_t* object_kind, rt_material* materials, double* spheres,
                                        int32_t* sphere_obj) {
   if (!s) {

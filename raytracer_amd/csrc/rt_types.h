@@ -40,7 +40,9 @@ struct alignas(16) BvhNode {
 // every lane of a wave fetches a different node, and what limits them is the number of load
 // instructions the texture addressers process, not arithmetic. The twelve planes are 16-bit
 // positions on a uniform grid over the scene's bounds (per axis: lo + q * step), rounded outward by
-// at least one grid step beyond the binary32 planes of BvhNode, so the boxes only grow.
+// at least one grid step beyond the binary32 planes of BvhNode, so the boxes only grow. Only scenes
+// for which that can be shown plane by plane get this copy (rt_quantize_tree, rt_host.cpp); the
+// others are walked through BvhNode everywhere.
 struct alignas(16) BvhNodeQ {
   uint16_t q[12];  // x: child0.min child0.max child1.min child1.max, then y, then z
   int32_t child[2];
@@ -178,6 +180,7 @@ unsigned rt_build_threads();
 void rt_add_into(double* dst, const double* src, size_t n);
 void rt_tile_texture(const HostTexture& t, std::vector<uint8_t>* out, uint32_t* blocks_x);
 void rt_scene_centre_bounds(const rt_scene* s, double clo[3], double chi[3]);
+bool rt_quantize_tree(const rt_scene* s, std::vector<BvhNodeQ>* out, float q_lo[3], float q_step[3]);
 // rt_device.hip
 void rt_device_scene_free(DeviceScene* d);
 int rt_device_scene_upload_from(const rt_scene* host, rt_scene* target, int device);

@@ -253,6 +253,18 @@ class Scene:
         check(lib.rt_scene_export_bvh(self._h, _ptr(nodes), _ptr(order)), "rt_scene_export_bvh")
         return nodes, order
 
+    def export_grid_bvh(self):
+        """The half-size copy of the tree the launches over the ray queue walk: (nodes as
+        [bvh_nodes][8] uint32, lo[3], step[3]), or None when the scene does not qualify for it."""
+        i = self.info()
+        nodes = np.zeros((i.bvh_nodes, 8), np.uint32)
+        lo_step = np.zeros(6, np.float32)
+        usable = C.c_int32()
+        check(lib.rt_scene_export_grid_bvh(self._h, _ptr(nodes), _ptr(lo_step), C.byref(usable)), "rt_scene_export_grid_bvh")
+        if not usable.value:
+            return None
+        return nodes, lo_step[:3].copy(), lo_step[3:].copy()
+
     # ---- device -----------------------------------------------------------------------
     def rebuild_on_device(self, device=0, method=None):
         """Replaces the host-built tree by one built on the GPU (for scenes that change):

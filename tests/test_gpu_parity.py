@@ -240,6 +240,50 @@ def test_render_variants_are_bitwise_identical(gpu_scenes, monkeypatch):
         monkeypatch.delenv("RT_LEAVE")
 
 
+def test_grid_nodes_and_binary32_nodes_give_the_same_bits(gpu_scenes, oracle, monkeypatch):
+    """The launches over the ray queue walk the 16-bit grid copy of the tree when the scene
+    qualifies for it, the binary32 nodes otherwise (RT_NO_GRID, read at upload, forces that): same
+    image, same rays. A scene shrunk until its coordinates are ten times its extent still
+    qualifies and must agree with the oracle; the same scene a thousand units off does not
+    qualify, and its hit records must."""
+    from test_grid_nodes import _moved
+
+    w, h, spp = 72, 40, 5
+    base = np.zeros((h, w, 3))
+    rays = gpu_scenes("spot").render(base, rt.render_params(width=w, height=h, spp=spp, seed=5))
+    monkeypatch.setenv("RT_NO_GRID", "1")
+    s2 = scenes.build("spot")
+    c = np.zeros((h, w, 3))
+    assert s2.render(c, rt.render_params(width=w, height=h, spp=spp, seed=5)) == rays
+    assert c.tobytes() == base.tobytes()
+    monkeypatch.delenv("RT_NO_GRID")
+
+    args = _moved("spot", scale=0.15, about=(0.0, 0.0, -3.0), drop_objects=(0,))
+    small = rt.Scene.from_desc(*args)
+    assert small.export_grid_bvh() is not None
+    o = oracle.OracleScene.from_desc_arrays(*args)
+    p = rt.render_params(width=96, height=72, spp=6, seed=3, fov_y_deg=12.0)
+    got = np.zeros((72, 96, 3)); want = np.zeros((72, 96, 3))
+    n_got = small.render(got, p)
+    n_want, _ = o.render(want, p)
+    assert n_got == n_want and n_got > 96 * 72 * 6 * 1.2, "the shrunk scene must be in view and scatter rays"
+    assert rel_err(got, want) < IMG_RTOL
+
+    args = _moved("spot", offset=(0.0, 1000.0, 0.0))
+    far = rt.Scene.from_desc(*args)
+    assert far.export_grid_bvh() is None
+    o = oracle.OracleScene.from_desc_arrays(*args)
+    rng = np.random.default_rng(23)
+    org = rng.normal(size=(4000, 3)) * 2.0 + np.array([0.0, 1000.5, -2.5]); d = rng.normal(size=(4000, 3))
+    hits = far.hit(org, d)
+    assert hits.tobytes() == o.hit(org, d).tobytes() and np.count_nonzero(hits["obj"] >= 0) > 1000
+    # and a frame of it (nothing but the floor's far edge in view: the queue launches still run)
+    got = np.zeros((30, 40, 3)); want = np.zeros((30, 40, 3))
+    p = rt.render_params(width=40, height=30, spp=2, seed=1)
+    assert far.render(got, p) == o.render(want, p)[0]
+    assert rel_err(got, want) < IMG_RTOL
+
+
 def test_emissive_materials(oracle):
     """Emission travels with the path (src/main.rs:925-929): an emissive floor under a grey sphere
     and a glass sphere, every scheduling form against the oracle."""

@@ -337,6 +337,13 @@ int rt_device_scene_upload_from(const rt_scene* s, rt_scene* target, int device)
   d->k.n_spheres = (uint32_t)s->spheres.size();
   d->k.has_emission = 0;
   {
+    // normalize((1, 2, 1)) as src/main.rs:87-90, 307 computes it: every component over the length
+    const double l = std::sqrt(1.0 * 1.0 + 2.0 * 2.0 + 1.0 * 1.0);
+    d->k.sky_light[0] = 1.0 / l;
+    d->k.sky_light[1] = 2.0 / l;
+    d->k.sky_light[2] = 1.0 / l;
+  }
+  {
     const char* e = std::getenv("RT_LEAVE");
     d->k.leave_q = e && *e ? std::max(0, std::min(64, std::atoi(e))) : RT_LEAVE_DEFAULT;
   }
@@ -832,7 +839,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_paths(SceneK sc, PathParams pp, do
       trace_ray<COUNT>(sc, o, dir, stk, stride, h, wc);
       bool finished;
       if (h.slot < 0 && h.sphere < 0) {
-        const d3 s = sky(dir);  // src/main.rs:826
+        const d3 s = sky(sc, dir);  // src/main.rs:826
         rad = rad + mk(thr.x * s.x, thr.y * s.y, thr.z * s.z);
         finished = true;
       } else {
@@ -1132,7 +1139,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
       wc.rays++;
       finish_hit<COUNT>(sc, o, dir, t.best_t, t.best_u, t.best_v, t.best_slot, h, wc);
       if (!(h.slot >= 0 || h.sphere >= 0)) {
-        const d3 s = sky(dir);  // src/main.rs:826
+        const d3 s = sky(sc, dir);  // src/main.rs:826
         rad = rad + mk(thr.x * s.x, thr.y * s.y, thr.z * s.z);
         store_sample(samples, pp.n_paths, path, rad);
         alive = false;

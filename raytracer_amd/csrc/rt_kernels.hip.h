@@ -133,6 +133,12 @@ struct Rng {
   __device__ __forceinline__ void skip(uint32_t n) { x += RT_GOLDEN * (uint64_t)n; }
 };
 
+// The point of the unit sphere an accepted candidate pair stands for, src/main.rs:272-277.
+__device__ __forceinline__ d3 marsaglia_point(double x1, double x2) {
+  const double sq = sqrt(1.0 - x1 * x1 - x2 * x2);
+  return mk(2.0 * x1 * sq, 2.0 * x2 * sq, 1.0 - 2.0 * (x1 * x1 + x2 * x2));
+}
+
 // random_unit_sphere_surface, src/main.rs:264-279 (Marsaglia), capped at RT_REJECT_CAP tries.
 __device__ __forceinline__ d3 random_unit_sphere_surface(Rng& r) {
   for (int tries = 0; tries < RT_REJECT_CAP; ++tries) {
@@ -164,6 +170,7 @@ struct SceneK {
   uint32_t n_spheres;
   uint32_t has_emission;  // some material has a non-zero emission
   int32_t leave_q;        // traversal: see trav_run
+  double sky_light[3];    // normalize((1, 2, 1)), src/main.rs:307
 };
 
 struct HitK {
@@ -503,11 +510,13 @@ __device__ __forceinline__ double pow6(double x) {
   return p6 + e6;
 }
 
-__device__ __forceinline__ d3 sky(const d3 dir) {
+__device__ __forceinline__ d3 sky(const SceneK& sc, const d3 dir) {
   const d3 c1 = mk(0.4, 0.6, 0.8);
   const d3 c2 = mk(0.8, 0.8, 0.8);
   const d3 light_c = mk(1.5, 1.5, 1.5);
-  const d3 light_dir = normalize(mk(1.0, 2.0, 1.0));
+  // normalize((1, 2, 1)), src/main.rs:307: the same three correctly rounded quotients whoever
+  // computes them, so the host does, once (sky_light_dir)
+  const d3 light_dir = mk(sc.sky_light[0], sc.sky_light[1], sc.sky_light[2]);
   double t = dot(dir, light_dir);
   t = pow6((t + 1.0) / 2.0);
   return (1.0 - t) * (dir.y * c2 + (1.0 - dir.y) * c1) + t * light_c;
@@ -582,7 +591,6 @@ __device__ __forceinline__ void shade_hit(const SceneK& sc, const ShadeIn& h, co
   }
   const rt_material* m = sc.mats + obj;
   const int kind = m->kind;
-  const d3 camera_dir = normalize(-1.0 * dir);  // src/main.rs:835
   Rng rng;
   rng.start(key, (uint32_t)depth + 1u);
 
@@ -612,70 +620,118 @@ __device__ __forceinline__ void shade_hit(const SceneK& sc, const ShadeIn& h, co
       point = mk(m->color[0], m->color[1], m->color[2]);
     }
     const double metallic = m->metallic, diffuse = m->diffuse, how_metallic = m->how_metallic;
-    // src/main.rs:851-857
-    const double cdn = dot(camera_dir, normal);
-    d3 r;
-    if (cdn < 0.0) {
-      r = -1.0 * camera_dir;
-    } else {
-      r = 2.0 * cdn * normal - camera_dir;
-    }
-    const d3 reflected_camera = normalize(r);
-    // src/main.rs:869-883 as ONE loop. The reference draws a Marsaglia point for the metal jitter
-    // (rejection loop 265-278), three unused uniforms (871-873), then Marsaglia points until one
-    // lies in the normal's hemisphere (876-883). Nested rejection loops cost a wave the maximum
-    // trip count of every level; this state machine consumes exactly the same draws in the same
-    // order, one pair per iteration, so a wave pays only the longest total.
-    d3 jit = mk(0.0, 0.0, 0.0);
-    d3 diffuse_out = mk(0.0, 0.0, 0.0);
+    // src/main.rs:925-929 unrolled: L = albedo * (L_in + emission)
+    thr = mk(thr.x * point.x, thr.y * point.y, thr.z * point.z);
+    rad = rad + mk(thr.x * m->emission[0], thr.y * m->emission[1], thr.z * m->emission[2]);
+    // src/main.rs:869-883. The reference draws a Marsaglia point for the metal jitter (rejection
+    // loop 265-278), three unused uniforms (871-873), then Marsaglia points until one lies in the
+    // normal's hemisphere (876-883). Here the same draws are consumed in the same order by two
+    // loops that only DECIDE — how many candidate pairs the jitter takes, which pair the hemisphere
+    // sample takes — and the points are built afterwards, once, from the chosen pairs.
     RT_ACC(wc, 0);
+    // (a) the jitter's pairs: up to and including the first whose squared length is below one
+    for (int tries = 0; tries < RT_REJECT_CAP; ++tries) {
+      if (COUNT && first_active_lane()) wc.wi_reject++;
+      double x1, x2;
+      rng.pair_pm1(x1, x2);
+      if (!(x1 * x1 + x2 * x2 >= 1.0)) break;
+    }
+    rng.skip(3);
+    // (b) the hemisphere sample. One loop over candidate pairs (nested loops would cost a wave the
+    // maximum trip count of every level): `inner` counts the pairs of the current Marsaglia call,
+    // `outer` the calls. Whether a point lies in the hemisphere is the sign of dot(point, normal) as
+    // the reference rounds it; the loop first forms that dot product with the hardware's
+    // approximate square root (v_sqrt_f64, 2^-23 relative) and fused operations, which is off by
+    // less than 2^-21 of |n.x| + |n.y| + |n.z|; only a value within 2^-20 of that sum of zero —
+    // about one candidate in a million — is settled by the reference's own arithmetic.
+    double x1 = 0.0, x2 = 0.0;
+    int b_kind = 0;  // 0: no point within the cap, 1: the point of (x1, x2), 2: a call's fallback point (0, 0, 1)
     {
-      int phase = 0, inner = 0, outer = 0;
+      const double doubt = (fabs(normal.x) + fabs(normal.y) + fabs(normal.z)) * 9.5367431640625e-07;  // 2^-20
+      int inner = 0, outer = 0;
       for (;;) {
         if (COUNT && first_active_lane()) wc.wi_reject++;
-        double x1, x2;
         rng.pair_pm1(x1, x2);
         inner += 1;
         const double r2 = x1 * x1 + x2 * x2;
         const bool accept = !(r2 >= 1.0);
         if (!accept && inner < RT_REJECT_CAP) continue;
-        d3 pt = mk(0.0, 0.0, 1.0);  // fallback after RT_REJECT_CAP rejections
-        if (accept) {
-          const double sq = sqrt(1.0 - x1 * x1 - x2 * x2);
-          pt = mk(2.0 * x1 * sq, 2.0 * x2 * sq, 1.0 - 2.0 * (x1 * x1 + x2 * x2));
-        }
         inner = 0;
-        if (phase == 0) {
-          jit = metallic * pt;
-          rng.skip(3);
-          phase = 1;
+        outer += 1;
+        bool inside;
+        if (accept) {
+          const double sq = __builtin_amdgcn_sqrt(1.0 - r2);
+          const double approx = __builtin_fma(2.0 * sq, __builtin_fma(normal.x, x1, normal.y * x2), normal.z * __builtin_fma(-2.0, r2, 1.0));
+          inside = approx > 0.0;
+          if (!(fabs(approx) > doubt)) inside = dot(marsaglia_point(x1, x2), normal) > 0.0;  // also when the normal is not finite
         } else {
-          outer += 1;
-          if (dot(pt, normal) > 0.0) {
-            diffuse_out = pt;
-            break;
-          }
-          if (outer >= RT_REJECT_CAP) break;
+          inside = dot(mk(0.0, 0.0, 1.0), normal) > 0.0;
         }
+        if (inside) {
+          b_kind = accept ? 1 : 2;
+          break;
+        }
+        if (outer >= RT_REJECT_CAP) break;
       }
     }
     RT_ACC(wc, 1);
+    d3 diffuse_out = mk(0.0, 0.0, 0.0);
+    if (b_kind == 1) diffuse_out = marsaglia_point(x1, x2);
+    if (b_kind == 2) diffuse_out = mk(0.0, 0.0, 1.0);
     diffuse_out = diffuse * diffuse_out + normal;  // src/main.rs:884
     if (length(diffuse_out) < eps) {
       diffuse_out = normal;
     } else {
       diffuse_out = normalize(diffuse_out);
     }
-    const d3 fuzzy_out = normalize(jit + reflected_camera);                              // src/main.rs:896
-    const d3 out_dir = how_metallic * fuzzy_out + (1.0 - how_metallic) * diffuse_out;  // src/main.rs:900
+    // src/main.rs:900: out = how_metallic * fuzzy + (1 - how_metallic) * diffuse_out. For a purely
+    // diffuse material (how_metallic == 0) that is (+-0) + diffuse_out = diffuse_out, bit for bit,
+    // provided the fuzzy mirror direction is finite and no component of diffuse_out is a zero (whose
+    // sign the sum could change); then the mirror direction — the viewing direction, its reflection,
+    // the jitter point and three normalisations — is not computed at all. It is finite when
+    //   * the incoming direction can be normalised (its squared length neither under- nor overflows):
+    //     c = normalize(-dir) is then a unit vector;
+    //   * r = 2 (c.n) n - c can be normalised: |r|^2 = 1 + 4 (c.n)^2 (|n|^2 - 1) >= 1 - 4 |n|^2 (1 - |n|^2),
+    //     which is at least 0.04 unless |n|^2 lies in [0.4, 0.6] (and r = -c when c.n < 0);
+    //   * the jitter is shorter than the unit mirror direction it is added to: |metallic| <= 1/2.
+    // Everything else takes the reference's full formula.
+    const double dd = dot(dir, dir), nn = dot(normal, normal);
+    const bool diffuse_only = how_metallic == 0.0 && fabs(metallic) <= 0.5 && dd > 1e-200 && dd < 1e200 && (nn < 0.4 || (nn > 0.6 && nn < 4.0)) &&
+                              diffuse_out.x != 0.0 && diffuse_out.y != 0.0 && diffuse_out.z != 0.0;
+    d3 out_dir = diffuse_out;
+    if (!diffuse_only) {
+      const d3 camera_dir = normalize(-1.0 * dir);  // src/main.rs:835
+      // src/main.rs:851-857
+      const double cdn = dot(camera_dir, normal);
+      d3 r;
+      if (cdn < 0.0) {
+        r = -1.0 * camera_dir;
+      } else {
+        r = 2.0 * cdn * normal - camera_dir;
+      }
+      const d3 reflected_camera = normalize(r);
+      // the jitter's point: the stage's draws once more from their start, as loop (a) took them
+      Rng again;
+      again.start(key, (uint32_t)depth + 1u);
+      d3 pt = mk(0.0, 0.0, 1.0);  // fallback after RT_REJECT_CAP rejections
+      for (int tries = 0; tries < RT_REJECT_CAP; ++tries) {
+        double j1, j2;
+        again.pair_pm1(j1, j2);
+        if (!(j1 * j1 + j2 * j2 >= 1.0)) {
+          pt = marsaglia_point(j1, j2);
+          break;
+        }
+      }
+      const d3 jit = metallic * pt;                                                 // src/main.rs:869
+      const d3 fuzzy_out = normalize(jit + reflected_camera);                       // src/main.rs:896
+      out_dir = how_metallic * fuzzy_out + (1.0 - how_metallic) * diffuse_out;     // src/main.rs:900
+    }
     o = hit_pos + eps * out_dir;                                                        // src/main.rs:903
     dir = out_dir;
-    // src/main.rs:925-929 unrolled: L = albedo * (L_in + emission)
-    thr = mk(thr.x * point.x, thr.y * point.y, thr.z * point.z);
-    rad = rad + mk(thr.x * m->emission[0], thr.y * m->emission[1], thr.z * m->emission[2]);
   } else {
     // Dielectric, src/main.rs:936-969
     const double ior = m->ior;
+    const d3 camera_dir = normalize(-1.0 * dir);  // src/main.rs:835
     const bool front_face = dot(normal, camera_dir) > 0.0;
     const d3 n = front_face ? normal : -1.0 * normal;
     const double eta = front_face ? 1.0 / ior : ior;

@@ -178,8 +178,6 @@ def main():
     for l in scene.last_launches():
         c = counted.setdefault(l.kind, [0, 0, 0])
         c[0] += l.rays; c[1] += l.node_visits; c[2] += l.tri_tests
-    for w_ in range(args.warmup):
-        run_step(w_, 0)
     if canvas is not None:
         canvas.zero_()
 
@@ -201,6 +199,15 @@ def main():
             c = timed.setdefault(l.kind, [0.0, 0, 0])
             c[0] += l.ms; c[1] += max(1, l.folded); c[2] += l.rays
 
+    # Warm-up frames run exactly as the timed ones (same flags: whatever a timed frame needs — work
+    # buffers, the events of its timed launches, the launch plan of its shape — exists afterwards),
+    # as a run of their own.
+    for w_ in range(args.warmup):
+        run_step(w_, step_flags)
+    if pipelined:
+        scene.wait()
+    if canvas is not None:
+        canvas.zero_()
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -252,131 +259,50 @@ def main():
         spot = scenes.build(s_name)
         spot.upload(device)
         s_canvas = torch.zeros((sH, sW, 3), dtype=torch.float64, device="cuda")
-        frames = 2
-        for k in range(1 + frames):  # one warm-up frame (allocates the work buffers), then the timed ones
-            if k == 1:
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-            spot.render_device(s_canvas.data_ptr(), rt.render_params(width=sW, height=sH, spp=s_spp, first_sample=k * s_spp, seed=0,
-                                                                     flags=_ffi.RT_FLAG_PIPELINE), stream)
+        # the per-ray means of this workload's kernels: one frame of the counting build (it also allocates the work buffers)
+        spot.render_device(s_canvas.data_ptr(), rt.render_params(width=sW, height=sH, spp=s_spp, first_sample=0, seed=0,
+                                                                 flags=_ffi.RT_FLAG_COUNT_WORK), stream)
+        s_cst = spot.last_stats()
+        s_per_ray = {"nodes": s_cst.node_visits / max(1, s_cst.rays), "tris": s_cst.tri_tests / max(1, s_cst.rays),
+                     "spheres": s_cst.sphere_tests / max(1, s_cst.rays), "shaded": s_cst.shaded_hits / max(1, s_cst.rays),
+                     "rays_per_path": s_cst.rays / max(1, s_cst.paths)}
+        s_counted = {}
+        for l in spot.last_launches():
+            c = s_counted.setdefault(l.kind, [0, 0, 0])
+            c[0] += l.rays; c[1] += l.node_visits; c[2] += l.tri_tests
+        frames = 5
+        s_flags = _ffi.RT_FLAG_PIPELINE | _ffi.RT_FLAG_TIMING
+        spot.render_device(s_canvas.data_ptr(), rt.render_params(width=sW, height=sH, spp=s_spp, first_sample=s_spp, seed=0, flags=s_flags), stream)
+        spot.wait()  # one warm-up frame as the timed ones are run; the timed frames are a run of their own
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(frames):
+            spot.render_device(s_canvas.data_ptr(), rt.render_params(width=sW, height=sH, spp=s_spp, first_sample=(2 + k) * s_spp, seed=0,
+                                                                     flags=s_flags), stream)
         spot.wait()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t1) / frames
-        s_rays = spot.last_stats().rays / (1 + frames)
+        s_rays_total = spot.last_stats().rays
+        s_timed = {}
+        for l in spot.last_launches():
+            if l.kind == 1 and l.items == 0 and not l.folded:
+                continue
+            c = s_timed.setdefault(l.kind, [0.0, 0, 0])
+            c[0] += l.ms; c[1] += max(1, l.folded); c[2] += l.rays
+        s_roof, s_kernels = roofline_block("spot_4k_256spp", s_timed, s_counted, s_cst, s_per_ray, frames, s_rays_total,
+                                           spot.export_grid_bvh() is not None, torch.cuda.get_device_properties(device))
+        s_rays = s_rays_total / frames
         secondary = {"metric": "sec/frame Spot 4K 256spp", "value": round(dt, 5), "unit": "s", "higher_is_better": False,
                      "workload": f"spot_4k_256spp: scene {s_name}, {sW}x{sH}, {s_spp} spp, depth cap 200",
-                     "frames_timed": frames, "mrays_per_s": round(s_rays / dt / 1e6, 1), "rays_per_frame": int(s_rays)}
+                     "frames_timed": frames, "mrays_per_s": round(s_rays / dt / 1e6, 1), "rays_per_frame": int(s_rays),
+                     "per_ray": {k: round(v, 3) for k, v in s_per_ray.items()}, "kernels": s_kernels, "roofline": s_roof}
         del spot, s_canvas
 
     if rank == 0:
         value = rays_all / elapsed / 1e6
-        # Roofline of the dominant kernel (largest total time in the timed region), against three
-        # candidate bounds; the headline fraction is the largest of them, i.e. the bound the kernel
-        # is closest to. Algorithmic work per ray, with that kernel's own per-ray means from the
-        # counting build: bytes = 64 B per interior node visited (32 B in the launches over the queue,
-        # which walk the half-size copy of the tree) + 192 B per triangle tested (72 B
-        # vertices + 72 B vertex normals + 48 B texture coordinates) + 48 B ray in + 40 B hit out;
-        # flops = 24 per node visit (binary32 slab tests of two boxes) + 52 per triangle test + 30
-        # per sphere test (binary64).
-        names = {0: "k_wave<false,0> (camera + trace + first bounce)", 1: "k_wave<false,1> (shade + trace, hit queue)",
-                 2: "k_wave<false,2> (tail loop)", 3: "k_paths (single-kernel form)", 4: "k_resolve"}
-        dom = max((k for k in timed if k != 4), key=lambda k: timed[k][0])
-        d_ms, d_launches, d_rays = timed[dom]
-        c_rays, c_nodes, c_tris = counted.get(dom, [cst.rays, cst.node_visits, cst.tri_tests])
-        if c_rays == 0:  # the single-kernel form logs no per-launch ray count when not counting
-            c_rays, c_nodes, c_tris = cst.rays, cst.node_visits, cst.tri_tests
-        if d_rays == 0:
-            d_rays = rays_total
-        # the launches over the queue (and the tail) walk the 32-byte copy of the nodes
-        node_bytes = 32.0 if dom in (1, 2) else 64.0
-        bytes_per_ray = node_bytes * c_nodes / c_rays + 192.0 * c_tris / c_rays + 88.0
-        f32_flops_per_ray = 24.0 * c_nodes / c_rays
-        f64_flops_per_ray = 52.0 * c_tris / c_rays + 30.0 * per_ray["spheres"]
-        flops_per_ray = f32_flops_per_ray + f64_flops_per_ray
-        launch_ms = d_ms / d_launches
-        launch_s = launch_ms * 1e-3
-        rays_per_launch = d_rays / d_launches
-        kernels = [
-            {"kernel": names[k], "launches_per_frame": round(v[1] / args.steps, 2), "ms_per_frame": round(v[0] / args.steps, 4),
-             "mrays_per_frame": round(v[2] / args.steps / 1e6, 3)}
-            for k, v in sorted(timed.items())
-        ]
-        ms_resolve = [timed.get(4, [0.0, 1, 0])[0] / max(1, timed.get(4, [0.0, 1, 0])[1])]
-        # Counter-derived figures of the dominant kernel (HBM bytes, VALU instructions) are replayed
-        # from the committed rocprofv3 PMC passes of this same command (profiles/hbm_traffic.json,
-        # stamped with the library revision they were taken on); durations are measured live.
-        traffic = None
-        valu_issue = None
-        counters_note = "none for this workload"
+        roofline, kernels = roofline_block(args.workload, timed, counted, cst, per_ray, args.steps, rays_total, scene.export_grid_bvh() is not None,
+                                           torch.cuda.get_device_properties(device))
         library_digest = (_ffi.lib.rt_source_digest() or b"unknown").decode()  # digest of the sources the library was built from
-        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tfile):
-            try:
-                tj = json.load(open(tfile))
-                pmc = tj.get(args.workload, {}).get(names[dom].split(" ")[0], {})
-                traffic = pmc.get("bytes_per_launch")
-                if traffic is not None:
-                    taken_on = tj.get("_library_digests", {}).get(args.workload, "unstamped")
-                    counters_note = (f"replayed from profiles/hbm_traffic.json, taken on library {taken_on} (git {tj.get('_library_revision', '?')}): "
-                                     + ("the library at hand" if taken_on == library_digest else f"STALE, the library at hand is {library_digest}"))
-                if pmc.get("valu_wave_insts_per_launch"):
-                    prop = torch.cuda.get_device_properties(device)
-                    simds = 4 * prop.multi_processor_count
-                    clock_ghz = (getattr(prop, "clock_rate", 0) or 0) / 1e6  # kHz -> GHz
-                    if not (1.0 < clock_ghz <= 2.4):
-                        clock_ghz = 2.4  # the MI355X's peak engine clock
-                    peak = simds * clock_ghz / 4.0  # a SIMD issues one wave64 binary64 instruction per 4 cycles
-                    ach = pmc["valu_wave_insts_per_launch"] / launch_s / 1e9
-                    valu_issue = {"achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instructions/s",
-                                  "frac": round(ach / peak, 4), "lane_use": pmc.get("valu_lane_use"),
-                                  "insts_per_ray": round(pmc["valu_wave_insts_per_launch"] * 64.0 / rays_per_launch, 1),
-                                  "note": "SQ_INSTS_VALU per launch (rocprofv3 PMC pass of this command, profiles/) over the live launch "
-                                          "duration, against 4 SIMDs x CUs x clock / 4 (the binary64 rate; binary32 and integer "
-                                          "instructions issue at twice that); lane_use = share of the 64 lanes active per VALU "
-                                          "instruction; insts_per_ray = lane-slots issued per ray"}
-            except Exception:
-                traffic = None
-        # (i) VALU: time the algorithmic flops would take at the vector peaks (binary32 slab tests at
-        # the FP32 peak, triangle and sphere tests at the FP64 peak) over the launch time
-        valu_s = rays_per_launch * (f32_flops_per_ray / (FP32_PEAK_TFLOPS * 1e12) + f64_flops_per_ray / (FP64_PEAK_TFLOPS * 1e12))
-        ach_tflops = flops_per_ray * rays_per_launch / launch_s / 1e12
-        cand = {
-            "valu": {"achieved": round(ach_tflops, 4), "peak": round(ach_tflops * launch_s / valu_s, 2), "unit": "TFLOP/s",
-                     "frac": round(valu_s / launch_s, 5),
-                     "note": f"{f32_flops_per_ray:.1f} binary32 + {f64_flops_per_ray:.1f} binary64 algorithmic flops per ray; peak = this mix at "
-                             f"{FP32_PEAK_TFLOPS} / {FP64_PEAK_TFLOPS} TFLOP/s vector"},
-            # (iii) cache: the algorithmic bytes are served by L1/L2 (the scene fits), so they are priced
-            # against the aggregate L2 bandwidth
-            "l2": {"achieved": round(bytes_per_ray * rays_per_launch / launch_s / 1e9, 2), "peak": L2_PEAK_GBS, "unit": "GB/s",
-                   "frac": round(bytes_per_ray * rays_per_launch / launch_s / 1e9 / L2_PEAK_GBS, 5),
-                   "note": "algorithmic bytes of every node visit and triangle test over the launch time, against the aggregate L2 bandwidth"},
-        }
-        if traffic is not None:  # (ii) HBM: measured bytes per launch
-            cand["hbm"] = {"achieved": round(traffic / launch_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(traffic / launch_s / 1e9 / HBM_PEAK_GBS, 5),
-                           "note": "measured HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE) over the live launch time"}
-        bound = max(cand, key=lambda k: cand[k]["frac"])
-        roofline = {
-            "kernel": names[dom],
-            "bound": bound,
-            "achieved": cand[bound]["achieved"],
-            "peak": cand[bound]["peak"],
-            "unit": cand[bound]["unit"],
-            "frac": cand[bound]["frac"],
-            "traffic": traffic,
-            "counters": counters_note,
-            "launch_ms": round(launch_ms, 4),
-            "bytes_per_ray": round(bytes_per_ray, 1),
-            "flops_per_ray": round(flops_per_ray, 1),
-            "rays_per_launch": int(rays_per_launch),
-            "launches_per_frame": round(d_launches / args.steps, 2),
-            "resolve_ms": round(float(np.mean(ms_resolve)), 4),
-            "candidates": cand,
-            "valu_issue": valu_issue,
-            "note": "frac is the largest of the candidate fractions (VALU flops at the vector peaks, algorithmic bytes at the aggregate L2 "
-                    "bandwidth, measured HBM bytes at the HBM peak): the bound the kernel is closest to. The scene's tree and triangles stay "
-                    "in cache, so HBM carries only the sample and queue writes",
-        }
         out = {
             "metric": "Mrays/s (primary+secondary)",
             "value": round(value, 2),
@@ -421,6 +347,148 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+KERNEL_NAMES = {0: "k_wave<false,0> (camera + trace + first bounce)", 1: "k_wave<false,1> (shade + trace, hit queue)",
+                2: "k_wave<false,2> (tail loop)", 3: "k_paths (single-kernel form)", 4: "k_resolve"}
+L2_LINE_BYTES = 128.0  # one L2 request moves at most one 128-byte line
+L1_ACCESS_BYTES = 64.0  # one vector-L1 access moves at most 64 bytes
+
+
+def roofline_block(workload, timed, counted, cst, per_ray, steps, rays_total, grid_nodes, prop):
+    """Roofline of the dominant kernel (largest total time among the timed launches) of a run.
+
+    Algorithmic work per ray, from that kernel's own per-ray means (counting build of the same
+    kernel): bytes = node bytes per interior node visited (64; 32 in the launches over the queue when
+    the scene qualifies for the half-size grid nodes) + 192 per triangle tested (72 vertices + 72
+    vertex normals + 48 texture coordinates: the reference's FlatTriangle and its per-hit lookups)
+    + 48 ray in + 40 hit out; fetch-only bytes = what the kernel's loads move: node bytes per visit
+    + 80 per triangle test (TriGeom) + 128 per shaded hit (TriShade) + 88. Flops = 24 per node visit
+    (binary32 slab tests of two boxes) + 52 per triangle test + 30 per sphere test (binary64).
+    Candidate bounds: VALU flops at the vector peaks; measured HBM bytes at the HBM peak;
+    algorithmic bytes at the aggregate L2 bandwidth (l2.algorithmic) next to what the L2 and the
+    vector L1s were actually asked for (l2.measured, l1.measured: request counters of the
+    committed PMC passes). frac is the largest of the candidate fractions."""
+    dom = max((k for k in timed if k != 4), key=lambda k: timed[k][0])
+    d_ms, d_launches, d_rays = timed[dom]
+    c_rays, c_nodes, c_tris = counted.get(dom, [cst.rays, cst.node_visits, cst.tri_tests])
+    if c_rays == 0:  # the single-kernel form logs no per-launch ray count when not counting
+        c_rays, c_nodes, c_tris = cst.rays, cst.node_visits, cst.tri_tests
+    if d_rays == 0:
+        d_rays = rays_total
+    # only the launches over the queue walk the 32-byte copy of the nodes, and only in scenes that qualify for it
+    node_bytes = 32.0 if (dom == 1 and grid_nodes) else 64.0
+    bytes_per_ray = node_bytes * c_nodes / c_rays + 192.0 * c_tris / c_rays + 88.0
+    fetch_bytes_per_ray = node_bytes * c_nodes / c_rays + 80.0 * c_tris / c_rays + 128.0 * per_ray["shaded"] + 88.0
+    f32_flops_per_ray = 24.0 * c_nodes / c_rays
+    f64_flops_per_ray = 52.0 * c_tris / c_rays + 30.0 * per_ray["spheres"]
+    flops_per_ray = f32_flops_per_ray + f64_flops_per_ray
+    launch_ms = d_ms / d_launches
+    launch_s = launch_ms * 1e-3
+    rays_per_launch = d_rays / d_launches
+    kernels = [
+        {"kernel": KERNEL_NAMES[k], "launches_per_frame": round(v[1] / steps, 2), "ms_per_frame": round(v[0] / steps, 4),
+         "mrays_per_frame": round(v[2] / steps / 1e6, 3)}
+        for k, v in sorted(timed.items())
+    ]
+    resolve = timed.get(4, [0.0, 1, 0])
+    # Counter-derived figures of the dominant kernel are replayed from the committed rocprofv3 PMC
+    # passes of this same command (profiles/hbm_traffic.json, stamped with the digest of the library
+    # they were taken on); durations are measured live.
+    traffic = None
+    valu_issue = None
+    pmc = {}
+    counters_note = "none for this workload"
+    library_digest = (_ffi_lib().rt_source_digest() or b"unknown").decode()
+    tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tfile):
+        try:
+            tj = json.load(open(tfile))
+            pmc = tj.get(workload, {}).get(KERNEL_NAMES[dom].split(" ")[0], {})
+            traffic = pmc.get("bytes_per_launch")
+            if traffic is not None:
+                taken_on = tj.get("_library_digests", {}).get(workload, "unstamped")
+                counters_note = (f"replayed from profiles/hbm_traffic.json, taken on library {taken_on} (git {tj.get('_library_revision', '?')}): "
+                                 + ("the library at hand" if taken_on == library_digest else f"STALE, the library at hand is {library_digest}"))
+            if pmc.get("valu_wave_insts_per_launch"):
+                simds = 4 * prop.multi_processor_count
+                clock_ghz = (getattr(prop, "clock_rate", 0) or 0) / 1e6  # kHz -> GHz
+                if not (1.0 < clock_ghz <= 2.4):
+                    clock_ghz = 2.4  # the MI355X's peak engine clock
+                peak = simds * clock_ghz / 4.0
+                ach = pmc["valu_wave_insts_per_launch"] / launch_s / 1e9
+                valu_issue = {"achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instructions/s",
+                              "frac": round(ach / peak, 4), "lane_use": pmc.get("valu_lane_use"),
+                              "insts_per_ray": round(pmc["valu_wave_insts_per_launch"] * 64.0 / rays_per_launch, 1),
+                              "note": "SQ_INSTS_VALU per launch (rocprofv3 PMC pass of this command, profiles/) over the live launch "
+                                      "duration, against 4 SIMDs x CUs x clock / 4: one wave-instruction per SIMD every 4 cycles, the rate "
+                                      "measured for binary64, 64-bit integer and 32-bit multiply instructions (4.2-4.8 cycles; 32-bit add and "
+                                      "logic instructions take 2.6: profiles/r03/valu_rates.txt); lane_use = share of the 64 lanes active per "
+                                      "VALU instruction; insts_per_ray = lane-slots issued per ray"}
+        except Exception:
+            traffic = None
+    # (i) VALU: time the algorithmic flops would take at the vector peaks (binary32 slab tests at
+    # the FP32 peak, triangle and sphere tests at the FP64 peak) over the launch time
+    valu_s = rays_per_launch * (f32_flops_per_ray / (FP32_PEAK_TFLOPS * 1e12) + f64_flops_per_ray / (FP64_PEAK_TFLOPS * 1e12))
+    ach_tflops = flops_per_ray * rays_per_launch / launch_s / 1e12
+    alg_gbs = bytes_per_ray * rays_per_launch / launch_s / 1e9
+    l2 = {"achieved": round(alg_gbs, 2), "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(alg_gbs / L2_PEAK_GBS, 5),
+          "algorithmic": {"bytes_per_ray": round(bytes_per_ray, 1), "gb_per_s": round(alg_gbs, 2), "frac": round(alg_gbs / L2_PEAK_GBS, 5)},
+          "fetch_only": {"bytes_per_ray": round(fetch_bytes_per_ray, 1), "gb_per_s": round(fetch_bytes_per_ray * rays_per_launch / launch_s / 1e9, 2),
+                         "frac": round(fetch_bytes_per_ray * rays_per_launch / launch_s / 1e9 / L2_PEAK_GBS, 5)},
+          "note": "algorithmic bytes of every node visit and triangle test over the launch time, against the aggregate L2 bandwidth; "
+                  "fetch_only counts what the kernel's loads move (80-byte triangle geometry per test, 128-byte shading record per hit); "
+                  "measured = requests the L2s actually received (TCC_HIT + TCC_MISS) x 128-byte line, an upper bound on the bytes they "
+                  "served: the tree and the triangles are mostly served by the CUs' vector L1s (l1_measured = TCP_TOTAL_CACHE_ACCESSES x 64 "
+                  "bytes, also an upper bound)"}
+    if pmc.get("tcc_requests_per_launch"):
+        gbs = pmc["tcc_requests_per_launch"] * L2_LINE_BYTES / launch_s / 1e9
+        l2["measured"] = {"requests_per_launch": int(pmc["tcc_requests_per_launch"]), "hit_rate": pmc.get("tcc_hit_rate"),
+                          "gb_per_s": round(gbs, 2), "frac": round(gbs / L2_PEAK_GBS, 5)}
+    if pmc.get("tcp_accesses_per_launch"):
+        gbs = pmc["tcp_accesses_per_launch"] * L1_ACCESS_BYTES / launch_s / 1e9
+        l2["l1_measured"] = {"accesses_per_launch": int(pmc["tcp_accesses_per_launch"]), "gb_per_s": round(gbs, 2),
+                             "bytes_per_ray": round(pmc["tcp_accesses_per_launch"] * L1_ACCESS_BYTES / rays_per_launch, 1)}
+    cand = {
+        "valu": {"achieved": round(ach_tflops, 4), "peak": round(ach_tflops * launch_s / valu_s, 2), "unit": "TFLOP/s",
+                 "frac": round(valu_s / launch_s, 5),
+                 "note": f"{f32_flops_per_ray:.1f} binary32 + {f64_flops_per_ray:.1f} binary64 algorithmic flops per ray; peak = this mix at "
+                         f"{FP32_PEAK_TFLOPS} / {FP64_PEAK_TFLOPS} TFLOP/s vector"},
+        "l2": l2,
+    }
+    if traffic is not None:  # (ii) HBM: measured bytes per launch
+        cand["hbm"] = {"achieved": round(traffic / launch_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": round(traffic / launch_s / 1e9 / HBM_PEAK_GBS, 5),
+                       "note": "measured HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE) over the live launch time"}
+    bound = max(cand, key=lambda k: cand[k]["frac"])
+    roofline = {
+        "kernel": KERNEL_NAMES[dom],
+        "bound": bound,
+        "achieved": cand[bound]["achieved"],
+        "peak": cand[bound]["peak"],
+        "unit": cand[bound]["unit"],
+        "frac": cand[bound]["frac"],
+        "traffic": traffic,
+        "counters": counters_note,
+        "launch_ms": round(launch_ms, 4),
+        "bytes_per_ray": round(bytes_per_ray, 1),
+        "flops_per_ray": round(flops_per_ray, 1),
+        "rays_per_launch": int(rays_per_launch),
+        "launches_per_frame": round(d_launches / steps, 2),
+        "resolve_ms": round(resolve[0] / max(1, resolve[1]), 4),
+        "candidates": cand,
+        "valu_issue": valu_issue,
+        "note": "frac is the largest of the candidate fractions (VALU flops at the vector peaks, algorithmic bytes at the aggregate L2 "
+                "bandwidth, measured HBM bytes at the HBM peak): the bound the kernel is closest to, not the share of the machine in use — the "
+                "scene's tree and triangles stay in the CUs' L1s, HBM carries only the sample and queue records, and what the kernel "
+                "actually runs out of is vector-instruction issue (valu_issue)",
+    }
+    return roofline, kernels
+
+
+def _ffi_lib():
+    from raytracer_amd import _ffi
+
+    return _ffi.lib
 
 
 def cpu_baseline(scene_name, W, H, spp, sample_spp):

@@ -120,6 +120,8 @@ pub struct rt_scene_info {
     pub bvh_leaves: u32,
     pub bvh_depth: u32,
     pub uploaded: u32,
+    pub bvh_spheres: u32,
+    pub reserved: u32,
     pub device_bytes: u64,
 }
 

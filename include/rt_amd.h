@@ -153,6 +153,8 @@ typedef struct rt_scene_info {
   uint32_t bvh_leaves;
   uint32_t bvh_depth;   /* longest root-to-leaf path, in nodes */
   uint32_t uploaded;    /* device index + 1, or 0              */
+  uint32_t bvh_spheres; /* spheres that have a place in the tree: the tree culls them like triangles */
+  uint32_t reserved;
   uint64_t device_bytes;
 } rt_scene_info;
 
@@ -284,7 +286,10 @@ int rt_scene_export_objects(const rt_scene* scene, int32_t* object_kind, rt_mate
 /* Size of texture `id`, and its [height][width][4] bytes if rgba is not NULL. */
 int rt_scene_export_texture(const rt_scene* scene, uint32_t id, uint32_t* width, uint32_t* height, uint8_t* rgba);
 /* Copies the acceleration structure out: nodes as bvh_nodes x 16 32-bit words (layout in
- * raytracer_amd/csrc/rt_types.h), and for each triangle slot in leaf order its flat index. */
+ * raytracer_amd/csrc/rt_types.h), and for each of the n_triangles + bvh_spheres slots in leaf order
+ * what sits there: a flat triangle index, or n_triangles + i for the place of sphere i (the tree
+ * culls the first 64 finite spheres like triangles, by their boxes; the sphere tests themselves
+ * run on the spheres whose place a ray reached). */
 int rt_scene_export_bvh(const rt_scene* scene, uint32_t* node_words, int32_t* leaf_order);
 /* No counterpart in the reference. The launches over the ray queue walk a half-size copy of the
  * tree whose planes are 16-bit positions on a grid over the scene's bounds; this copies it out:

@@ -1167,9 +1167,12 @@ inline float f32_up(double x) {  // smallest float >= x
   return f;
 }
 
+// leaf_order entries from tris.size() on are places of spheres in the tree (entry - tris.size() =
+// sphere index): their visit counts as a triangle test (the kernel runs one, on all-zero geometry,
+// which fails) and sets the sphere's bit in *sphere_mask.
 void bvh_trace(const uint32_t* node_words, uint32_t n_nodes, int32_t root_ref, const int32_t* leaf_order,
                const std::vector<FlatTriangle>& tris, const Vec3& origin, const Vec3& dir, double* best_t,
-               double* best_u, double* best_v, int64_t* best_flat, BvhCounts* counts) {
+               double* best_u, double* best_v, int64_t* best_flat, BvhCounts* counts, uint64_t* sphere_mask = nullptr) {
   const float K_FAR = 1.0f + 9.5367431640625e-07f;  // 1 + 2^-20
   float m_lo[3], m_hi[3], inv[3];
   double omax = std::fmax(std::fabs(origin.c[0]), std::fmax(std::fabs(origin.c[1]), std::fabs(origin.c[2])));
@@ -1245,8 +1248,12 @@ void bvh_trace(const uint32_t* node_words, uint32_t n_nodes, int32_t root_ref, c
     uint32_t first = leaf >> 2, cnt = (leaf & 3u) + 1u;
     for (uint32_t i = 0; i < cnt; ++i) {
       int32_t flat = leaf_order[first + i];
-      const FlatTriangle& ft = tris[flat];
       if (counts) counts->tris++;
+      if ((size_t)flat >= tris.size()) {
+        if (sphere_mask) *sphere_mask |= 1ull << (((size_t)flat - tris.size()) & 63u);
+        continue;
+      }
+      const FlatTriangle& ft = tris[flat];
       double t, u, v;
       if (intersects_triangle(origin, dir, ft.vertices[0], ft.vertices[1], ft.vertices[2], &t, &u, &v)) {
         if (t < *best_t || (t == *best_t && flat < *best_flat)) {
@@ -1526,6 +1533,26 @@ void orc_bvh_trace(orc_scene* sc, const uint32_t* node_words, uint32_t n_nodes, 
   std::atomic<size_t> next(0);
   std::atomic<uint64_t> cn(0), ct(0);
   const Scene& s = sc->s;
+  // the spheres that have a place in this tree (the others are tested against every ray)
+  uint64_t in_tree = 0;
+  size_t n_spheres = 0;
+  for (const Object& ob : s.objects) n_spheres += ob.kind == RT_OBJ_SPHERE ? 1 : 0;
+  size_t n_slots = 0;
+  {
+    // slots = highest slot any leaf names + 1
+    auto leaf_end = [&](int32_t ref) {
+      if (ref >= 0 || ref == INT32_MIN) return;
+      const uint32_t leaf = (uint32_t)~ref;
+      n_slots = std::max(n_slots, (size_t)(leaf >> 2) + (leaf & 3u) + 1u);
+    };
+    leaf_end(root_ref);
+    for (uint32_t k = 0; k < n_nodes; ++k) {
+      leaf_end((int32_t)node_words[(size_t)k * 16 + 12]);
+      leaf_end((int32_t)node_words[(size_t)k * 16 + 13]);
+    }
+  }
+  for (size_t k = 0; k < n_slots; ++k)
+    if ((size_t)leaf_order[k] >= s.triangles.size()) in_tree |= 1ull << (((size_t)leaf_order[k] - s.triangles.size()) & 63u);
   auto worker = [&]() {
     BvhCounts bc;
     for (;;) {
@@ -1535,10 +1562,11 @@ void orc_bvh_trace(orc_scene* sc, const uint32_t* node_words, uint32_t n_nodes, 
       for (size_t i = b; i < e; ++i) {
         Vec3 o = V(org3[i * 3], org3[i * 3 + 1], org3[i * 3 + 2]), d = V(dir3[i * 3], dir3[i * 3 + 1], dir3[i * 3 + 2]);
         Hit h;
-        if (!s.triangles.empty()) {
+        uint64_t reached = 0;
+        if (root_ref != INT32_MIN) {
           double t, u = 0, v = 0;
           int64_t flat;
-          bvh_trace(node_words, n_nodes, root_ref, leaf_order, s.triangles, o, d, &t, &u, &v, &flat, &bc);
+          bvh_trace(node_words, n_nodes, root_ref, leaf_order, s.triangles, o, d, &t, &u, &v, &flat, &bc, &reached);
           if (flat >= 0) {
             h.some = true;
             h.distance = t;
@@ -1548,9 +1576,13 @@ void orc_bvh_trace(orc_scene* sc, const uint32_t* node_words, uint32_t n_nodes, 
             h.obj_idx = s.triangles[flat].obj_idx;
           }
         }
+        size_t sphere_index = 0;
         for (size_t oi = 0; oi < s.objects.size(); ++oi) {
           const Object& ob = s.objects[oi];
           if (ob.kind != RT_OBJ_SPHERE) continue;
+          const size_t si = sphere_index++;
+          // a sphere with a place in the tree is tested only if the ray reached that place
+          if (si < 64 && ((in_tree >> si) & 1u) && !((reached >> si) & 1u)) continue;
           double t;
           if (intersects_sphere(ob.center, ob.radius, o, d, &t)) {
             double cur = h.some ? h.distance : std::numeric_limits<double>::infinity();

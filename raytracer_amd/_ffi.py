@@ -112,6 +112,8 @@ class rt_scene_info(C.Structure):
         ("bvh_leaves", C.c_uint32),
         ("bvh_depth", C.c_uint32),
         ("uploaded", C.c_uint32),
+        ("bvh_spheres", C.c_uint32),
+        ("reserved", C.c_uint32),
         ("device_bytes", C.c_uint64),
     ]
 

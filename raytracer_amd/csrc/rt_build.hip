@@ -524,8 +524,10 @@ static int rt_scene_rebuild_on_device_body(rt_scene* s, int device, uint32_t met
     rt_set_error("rt_scene_rebuild_on_device: device %d out of range (0..%d)", device, n_dev - 1);
     return RT_ERR_INVALID;
   }
-  const size_t n = s->tri_obj.size();
-  if (n == 0) return RT_OK;  // spheres only: there is no tree
+  rt_scene_pick_tree_spheres(s);
+  const size_t n_tri = s->tri_obj.size();
+  const size_t n = n_tri + s->tree_spheres.size();  // triangles, then the places of the spheres the tree culls
+  if (n == 0) return RT_OK;  // nothing to build over
   HIP_TRY_B(hipSetDevice(device));
   const bool timing = std::getenv("RT_BUILD_TIMING") != nullptr;
   auto t_last = std::chrono::steady_clock::now();
@@ -572,7 +574,12 @@ static int rt_scene_rebuild_on_device_body(rt_scene* s, int device, uint32_t met
       (rc = mem.get(&d_parent_leaf, n)) || (rc = mem.get(&d_visits, ni + 1)) || (rc = mem.get(&d_stats, 2)) ||
       (rc = mem.get(&d_nodes, ni)))
     return rc;
-  HIP_TRY_B(hipMemcpy(d_verts, s->tri_vertices.data(), n * 9 * sizeof(double), hipMemcpyHostToDevice));
+  if (n_tri) HIP_TRY_B(hipMemcpy(d_verts, s->tri_vertices.data(), n_tri * 9 * sizeof(double), hipMemcpyHostToDevice));
+  if (n > n_tri) {
+    std::vector<double> places((n - n_tri) * 9);
+    for (size_t k = 0; k < n - n_tri; ++k) rt_sphere_place_vertices(s->spheres[(size_t)s->tree_spheres[k]], &places[k * 9]);
+    HIP_TRY_B(hipMemcpy(d_verts + n_tri * 9, places.data(), places.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
   phase("copy in");
   const uint32_t grid_n = (uint32_t)((n + BUILD_BLOCK - 1) / BUILD_BLOCK);
   hipLaunchKernelGGL(k_boxes_codes, dim3(grid_n), dim3(BUILD_BLOCK), 0, nullptr, d_verts, (uint32_t)n, clo[0], clo[1], clo[2], scale[0],
@@ -673,6 +680,8 @@ static int rt_scene_rebuild_on_device_body(rt_scene* s, int device, uint32_t met
     leaves = stats[0];
   }
   HIP_TRY_B(hipMemcpy(leaf_order.data(), order_on_device ? d_leaf_order : d_vals_sorted, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  for (int32_t& e : leaf_order)  // the k-th sphere of the tree -> n_triangles + its sphere index
+    if ((size_t)e >= n_tri) e = (int32_t)(n_tri + (size_t)s->tree_spheres[(size_t)e - n_tri]);
   phase("copy out");
 
   // the scene takes the new tree; its device copy, if any, is stale

@@ -333,6 +333,15 @@ int rt_device_scene_upload_from(const rt_scene* s, rt_scene* target, int device)
     trec[i] = TextureRec{px, s->textures[i].w, s->textures[i].h, blocks_x};
   }
   if ((rc = upload_array(d, trec.data(), trec.size(), &d->k.tex)) != RT_OK) return fail(rc);
+  {
+    // spheres among the first 64 that have no place in the tree: tested against every ray
+    unsigned long long in_tree = 0ull;
+    for (int32_t i : s->tree_spheres) in_tree |= 1ull << (uint32_t)i;
+    const size_t n_low = std::min<size_t>(s->spheres.size(), (size_t)RT_TREE_SPHERES);
+    const unsigned long long low = n_low >= 64 ? ~0ull : ((1ull << n_low) - 1ull);
+    d->k.sph_always = low & ~in_tree;
+    d->k.sph_places = in_tree != 0ull ? 1u : 0u;
+  }
   d->k.root_ref = s->root_ref;
   d->k.n_spheres = (uint32_t)s->spheres.size();
   d->k.has_emission = 0;
@@ -560,6 +569,18 @@ static int finish_run(DeviceScene* d) {
 // kernels
 // ------------------------------------------------------------------------------------------
 extern __shared__ int32_t g_stack[];  // [stack_entries][blockDim.x]
+#ifdef RT_STAMPS
+// Diagnostic build only: cycles of wave lifetime by code section and kernel stage, summed over waves.
+__device__ unsigned long long g_stamps[3][RT_NSEC];
+extern "C" int rt_debug_stamps(unsigned long long* out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 3 * RT_NSEC) != hipSuccess) return RT_ERR_HIP;
+  if (reset) {
+    unsigned long long zero[3 * RT_NSEC] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zero, sizeof zero) != hipSuccess) return RT_ERR_HIP;
+  }
+  return RT_OK;
+}
+#endif
 
 __device__ __forceinline__ uint32_t linear_block() { return blockIdx.y * gridDim.x + blockIdx.x; }
 
@@ -1054,6 +1075,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
   const int lane = threadIdx.x & 63;
   WorkCount wc{};
   uint32_t n_done = 0, n_vb = 0;
+#ifdef RT_STAMPS
+  if (lane == 0) {
+    for (int i = 0; i < RT_NSEC; ++i) s_stamp[threadIdx.x >> 6][i] = 0ull;
+    s_stamp[threadIdx.x >> 6][RT_NSEC] = clock64();
+  }
+#endif
   // Stage 0: one block of paths per workgroup. Later stages: record blocks of the workgroup's
   // segment, as many as the plan says there are.
   uint32_t hit_blocks = 0, vb_end = 1;
@@ -1137,7 +1164,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
       trav_run<COUNT, QUANT>(t, sc, stride, wc);
       steps = t.steps;
       wc.rays++;
-      finish_hit<COUNT>(sc, o, dir, t.best_t, t.best_u, t.best_v, t.best_slot, h, wc);
+      finish_hit<COUNT>(sc, t, h, wc);
       if (!(h.slot >= 0 || h.sphere >= 0)) {
         const d3 s = sky(sc, dir);  // src/main.rs:826
         rad = rad + mk(thr.x * s.x, thr.y * s.y, thr.z * s.z);
@@ -1227,6 +1254,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
   if (!LOOP || STAGE == 0) break;  // the first stage has one block of paths per workgroup
   }  // record blocks of this workgroup
   flush_counts(wc, counters, COUNT, n_done, n_vb);
+#ifdef RT_STAMPS
+  RT_ACC(wc, 7);
+  if (lane == 0)
+    for (int i = 0; i < RT_NSEC; ++i) atomicAdd(&g_stamps[STAGE][i], s_stamp[threadIdx.x >> 6][i]);
+#endif
 }
 
 // Copies the records still queued (both runs of every segment: front and back) into

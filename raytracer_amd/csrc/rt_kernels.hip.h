@@ -171,6 +171,8 @@ struct SceneK {
   uint32_t has_emission;  // some material has a non-zero emission
   int32_t leave_q;        // traversal: see trav_run
   double sky_light[3];    // normalize((1, 2, 1)), src/main.rs:307
+  unsigned long long sph_always;  // bit i: sphere i (< 64) has no place in the tree and is tested against every ray
+  uint32_t sph_places;            // some sphere has a place in the tree
 };
 
 struct HitK {
@@ -250,6 +252,7 @@ struct Trav {
   int32_t cur;   // next node/leaf ref, RT_REF_SENTINEL when the traversal has finished
   int32_t* sp;   // top of the stack column (entries are `stride` ints apart)
   int32_t steps; // interior nodes this ray has visited
+  unsigned long long spheres;  // bit i: the ray reached the place of sphere i in the tree
 };
 
 // Culling ray: t = b * inv - (o -+ pad) * inv, one fused operation per plane (culling only; the
@@ -307,6 +310,7 @@ __device__ __forceinline__ void trav_begin(Trav& t, const SceneK& sc, const d3 o
   *t.sp = RT_REF_SENTINEL;
   t.cur = sc.root_ref;
   t.steps = 0;
+  t.spheres = 0ull;
 }
 
 // Runs the traversal to its end (t.cur == RT_REF_SENTINEL).
@@ -322,7 +326,9 @@ __device__ __forceinline__ void trav_run(Trav& t, const SceneK& sc, const int st
   int32_t cur = t.cur;
   int32_t* sp = t.sp;
   int steps = 0;
+  unsigned long long spheres = t.spheres;
 
+  RT_ACC(wc, 2);
   while (cur != RT_REF_SENTINEL) {
     RT_ACC(wc, 5);
     // The lanes that have reached a leaf wait for the others to reach theirs, but not for a few
@@ -410,6 +416,8 @@ __device__ __forceinline__ void trav_run(Trav& t, const SceneK& sc, const int st
       const d3 a_to_c = mk(g->ac[0], g->ac[1], g->ac[2]);
       const int32_t flat = g->flat;
       if (COUNT) wc.tris++;
+      // a sphere's place in the tree (all-zero geometry: the test below fails by itself): note the sphere
+      if (sc.sph_places && flat < 0) spheres |= 1ull << ((uint32_t)~flat & 63u);
       // intersects_triangle, src/main.rs:187-239
       const d3 u_vec = cross(d, a_to_c);
       const double det = dot(a_to_b, u_vec);
@@ -446,41 +454,71 @@ __device__ __forceinline__ void trav_run(Trav& t, const SceneK& sc, const int st
   t.cur = cur;
   t.sp = sp;
   t.steps = steps;
+  t.spheres = spheres;
 }
 
-// The sphere loop of Scene::hit, src/main.rs:802-810, on top of the nearest mesh hit.
-template <bool COUNT>
-__device__ __forceinline__ void finish_hit(const SceneK& sc, const d3 o, const d3 d, double best_t, double best_u,
-                                           double best_v, int32_t best_slot, HitK& h, WorkCount& wc) {
+// intersects_sphere, src/main.rs:241-262, for sphere i, and Scene::hit's "strictly nearer replaces"
+// (src/main.rs:805).
+__device__ __forceinline__ void test_sphere(const SceneK& sc, uint32_t i, const d3 o, const d3 d, HitK& h) {
   const double eps = 0.00000001;
-  h.t = best_t;
-  h.u = best_u;
-  h.v = best_v;
-  h.slot = best_slot;
-  h.sphere = -1;
-  // every sphere, in object order; strictly nearer replaces
-  for (uint32_t i = 0; i < sc.n_spheres; ++i) {
-    const SphereRec* s = sc.spheres + i;
-    if (COUNT) wc.spheres++;
-    // intersects_sphere, src/main.rs:241-262
-    const d3 oc = o - mk(s->c[0], s->c[1], s->c[2]);
-    const double a = dot(d, d);
-    const double half_b = dot(oc, d);
-    const double c = dot(oc, oc) - s->r * s->r;
-    const double discriminant = half_b * half_b - a * c;
-    if (discriminant < 0.0) continue;
-    const double sqrtd = sqrt(discriminant);
-    double root = (-half_b - sqrtd) / a;
-    if (root < eps) {
-      root = (-half_b + sqrtd) / a;
-      if (root < eps) continue;
-    }
-    if (root < h.t) {
-      h.t = root;
-      h.slot = -1;
-      h.sphere = (int32_t)i;
-    }
+  const SphereRec* s = sc.spheres + i;
+  const d3 oc = o - mk(s->c[0], s->c[1], s->c[2]);
+  const double a = dot(d, d);
+  const double half_b = dot(oc, d);
+  const double c = dot(oc, oc) - s->r * s->r;
+  const double discriminant = half_b * half_b - a * c;
+  if (discriminant < 0.0) return;
+  const double sqrtd = sqrt(discriminant);
+  double root = (-half_b - sqrtd) / a;
+  if (root < eps) {
+    root = (-half_b + sqrtd) / a;
+    if (root < eps) return;
   }
+  // strictly nearer replaces, so of two spheres at the same distance the one tested first — the
+  // lower index — wins in the reference; written so that it wins here in whatever order they are tested
+  if (root < h.t || (root == h.t && h.sphere > (int32_t)i)) {
+    h.t = root;
+    h.slot = -1;
+    h.sphere = (int32_t)i;
+  }
+}
+
+// The sphere loop of Scene::hit, src/main.rs:802-810, on top of the nearest mesh hit: spheres in
+// object order, strictly nearer replaces. The reference runs the test, with its square root and
+// one or two divisions, on every sphere for every ray. Here the tree culls spheres as it culls
+// triangles: a sphere has a place in a leaf, found by its bounding box, and only the spheres whose
+// place the ray reached (t.spheres) are tested — a ray cannot hit a sphere without entering its
+// box. Spheres without a place (not finite, or beyond the 64 the mask has bits for:
+// sc.sph_always and the indices from 64 on) are tested always.
+template <bool COUNT>
+__device__ __forceinline__ void finish_hit(const SceneK& sc, const Trav& t, HitK& h, WorkCount& wc) {
+  const d3 o = t.o, d = t.d;
+  h.t = t.best_t;
+  h.u = t.best_u;
+  h.v = t.best_v;
+  h.slot = t.best_slot;
+  h.sphere = -1;
+  // (a) the spheres every ray tests: the same index in every lane, so the record is read once per
+  // wave into scalar registers
+  const uint32_t n_low = min(sc.n_spheres, (uint32_t)RT_TREE_SPHERES);
+  for (uint32_t i = 0; i < n_low; ++i) {
+    if (!((sc.sph_always >> i) & 1ull)) continue;
+    if (COUNT) wc.spheres++;
+    test_sphere(sc, i, o, d, h);
+  }
+  // (b) the spheres whose place this ray reached
+  unsigned long long mask = sc.sph_places ? t.spheres : 0ull;
+  while (mask) {
+    const uint32_t i = (uint32_t)__ffsll((long long)mask) - 1u;
+    mask &= mask - 1ull;
+    if (COUNT) wc.spheres++;
+    test_sphere(sc, i, o, d, h);
+  }
+  for (uint32_t i = (uint32_t)RT_TREE_SPHERES; i < sc.n_spheres; ++i) {
+    if (COUNT) wc.spheres++;
+    test_sphere(sc, i, o, d, h);
+  }
+  RT_ACC(wc, 6);
 }
 
 template <bool COUNT>
@@ -489,7 +527,7 @@ __device__ __forceinline__ void trace_ray(const SceneK& sc, const d3 o, const d3
   Trav t;
   trav_begin(t, sc, o, d, stk);
   trav_run<COUNT>(t, sc, stride, wc);
-  finish_hit<COUNT>(sc, o, d, t.best_t, t.best_u, t.best_v, t.best_slot, h, wc);
+  finish_hit<COUNT>(sc, t, h, wc);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -630,6 +668,9 @@ __device__ __forceinline__ void shade_hit(const SceneK& sc, const ShadeIn& h, co
     // sample takes — and the points are built afterwards, once, from the chosen pairs.
     RT_ACC(wc, 0);
     // (a) the jitter's pairs: up to and including the first whose squared length is below one
+    // (not unrolled: four in five lanes are done after the first pair, and a wave issues every
+    // instruction of an unrolled body for the one lane that is not)
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
     for (int tries = 0; tries < RT_REJECT_CAP; ++tries) {
       if (COUNT && first_active_lane()) wc.wi_reject++;
       double x1, x2;
@@ -714,6 +755,7 @@ __device__ __forceinline__ void shade_hit(const SceneK& sc, const ShadeIn& h, co
       Rng again;
       again.start(key, (uint32_t)depth + 1u);
       d3 pt = mk(0.0, 0.0, 1.0);  // fallback after RT_REJECT_CAP rejections
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
       for (int tries = 0; tries < RT_REJECT_CAP; ++tries) {
         double j1, j2;
         again.pair_pm1(j1, j2);

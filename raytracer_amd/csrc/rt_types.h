@@ -11,6 +11,12 @@
 //   rt_material     one per object (include/rt_amd.h)
 //
 // TriGeom and TriShade are stored in leaf order: a leaf names a run of 1..4 consecutive slots.
+//
+// Spheres are not triangles, but the tree culls them like triangles: each of the first
+// RT_TREE_SPHERES finite spheres has a slot in some leaf, placed by its bounding box. The slot's
+// TriGeom is all zeros (its triangle test can never succeed) with flat = ~sphere index, which tells
+// the traversal to note the sphere as a candidate; the sphere tests themselves run after the
+// traversal, on the candidates only, in object order (src/main.rs:802-810 tests every sphere).
 #ifndef RT_TYPES_H
 #define RT_TYPES_H
 
@@ -25,6 +31,7 @@
 #define RT_BVH_MAX_DEPTH 62           /* builder guarantee; the traversal stack is sized by it */
 #define RT_REF_SENTINEL INT32_MIN     /* bottom of the traversal stack / empty tree          */
 #define RT_REJECT_CAP 64              /* tries per rejection loop before the fallback        */
+#define RT_TREE_SPHERES 64            /* spheres that can have a place in the tree (one bit each in a ray's candidate mask) */
 
 // A child ref >= 0 is the index of an interior node. A ref < 0 other than RT_REF_SENTINEL is a
 // leaf: ~ref = first_slot * RT_LEAF_MAX + (count - 1).
@@ -119,7 +126,8 @@ struct rt_scene {
   std::vector<HostTexture> textures;
   // acceleration structure
   std::vector<BvhNode> nodes;
-  std::vector<int32_t> leaf_order;  // slot -> flat index
+  std::vector<int32_t> leaf_order;  // slot -> flat triangle index, or n_triangles + sphere index for a sphere's place in the tree
+  std::vector<int32_t> tree_spheres;  // the spheres that have a place in the tree (ascending sphere indices)
   std::vector<TriGeom> tri_geom;    // leaf order
   std::vector<TriShade> tri_shade;  // leaf order
   int32_t root_ref = RT_REF_SENTINEL;
@@ -175,6 +183,8 @@ static inline bool rt_parse_u64(const std::string& t, uint64_t* v) {
   return r.ec == std::errc() && r.ptr == e && *b != '+' && *b != '-';
 }
 void rt_fill_leaf_records(rt_scene* s);
+void rt_scene_pick_tree_spheres(rt_scene* s);
+void rt_sphere_place_vertices(const SphereRec& sp, double v9[9]);
 double rt_scene_box_pad(const rt_scene* s);
 unsigned rt_build_threads();
 void rt_add_into(double* dst, const double* src, size_t n);

@@ -249,7 +249,7 @@ class Scene:
     def export_bvh(self):
         i = self.info()
         nodes = np.zeros((i.bvh_nodes, 16), np.uint32)
-        order = np.zeros(i.n_triangles, np.int32)
+        order = np.zeros(i.n_triangles + i.bvh_spheres, np.int32)
         check(lib.rt_scene_export_bvh(self._h, _ptr(nodes), _ptr(order)), "rt_scene_export_bvh")
         return nodes, order
 

@@ -108,6 +108,75 @@ def test_trace_edge_cases(gpu_scenes, oracle):
     assert got.tobytes() == want.tobytes() and got["tri"][0] == -1 and got["t"][0] == 0.5
 
 
+def _sphere_rays(rng, spheres, n):
+    """Rays that graze, leave, cross and start inside the spheres: the cases in which the box around
+    the spheres and the early exits of the sphere test (negative discriminant; both roots behind
+    the origin) decide."""
+    org, d = [], []
+    for c4 in spheres:
+        c, r = c4[:3], c4[3]
+        for _ in range(n):
+            o = c + rng.normal(size=3) * r * rng.choice([0.5, 1.5, 4.0, 40.0])
+            # towards a point on or just off the silhouette
+            u = rng.normal(size=3); u /= np.linalg.norm(u)
+            to_c = c - o
+            side = np.cross(to_c, u); side /= max(np.linalg.norm(side), 1e-300)
+            target = c + side * r * rng.choice([0.0, 0.999999, 1.0, 1.000001, 1.0 + 1e-12, 1.0 - 1e-12, 2.0])
+            org.append(o); d.append((target - o) * rng.choice([1.0, 1e-3, 1e3, 1e-9]))
+            # the same ray backwards: the sphere lies behind the origin
+            org.append(o); d.append(o - target)
+            # from the surface, outwards and inwards, as scattered rays start (src/main.rs:903)
+            p = c + u * r
+            w = rng.normal(size=3); w /= np.linalg.norm(w)
+            org.append(p + 1e-8 * w); d.append(w)
+            org.append(p); d.append(-u + 0.3 * w)
+    return np.array(org), np.array(d)
+
+
+def test_sphere_culling_keeps_every_hit(gpu_scenes, oracle, monkeypatch):
+    s = gpu_scenes("spot")
+    o = oracle.OracleScene.build("spot")
+    rng = np.random.default_rng(29)
+    _, _, sph, _ = s.export_objects()
+    org, d = _sphere_rays(rng, sph, 400)
+    got = s.hit(org, d)
+    want = o.hit(org, d)
+    assert got.tobytes() == want.tobytes()
+    assert np.count_nonzero(got["tri"] == -1) > 2000 and np.count_nonzero(got["obj"] < 0) > 1000
+    # the six spheres given places in the tree (by default only scenes of nine spheres or more do that;
+    # read when the tree is built): a ray then tests the spheres whose place it reached instead of
+    # all of them — the same records, the same image
+    monkeypatch.setenv("RT_SPHERE_TREE_FROM", "1")
+    s2 = scenes.build("spot")
+    assert s2.info().bvh_spheres == 6 and s.info().bvh_spheres == 0
+    assert s2.hit(org, d).tobytes() == want.tobytes()
+    w, h, spp = 72, 40, 5
+    a = np.zeros((h, w, 3)); b = np.zeros((h, w, 3))
+    assert s.render(a, rt.render_params(width=w, height=h, spp=spp, seed=5)) == s2.render(b, rt.render_params(width=w, height=h, spp=spp, seed=5))
+    assert a.tobytes() == b.tobytes()
+    monkeypatch.delenv("RT_SPHERE_TREE_FROM")
+    # spheres only, more of them than the candidate mask has bits (72 > 64), one of them not finite
+    k = 72
+    cen = rng.normal(size=(k, 3)) * 2.0 + np.array([0.0, 0.0, -6.0])
+    sph = np.concatenate([cen, rng.uniform(0.1, 0.6, size=(k, 1))], axis=1)
+    mat = rt.Opaque((0.5, 0.5, 0.5), 0, 1, 0)
+    for variant in ("finite", "one infinite radius"):
+        if variant != "finite":
+            sph[5, 3] = np.inf
+        args = ([_ffi.RT_OBJ_SPHERE] * k, [mat] * k, np.zeros((0, 9)), [], [], [], [], sph, list(range(k)))
+        many = rt.Scene.from_desc(*args)
+        assert many.info().bvh_spheres == (64 if variant == "finite" else 63) and many.info().bvh_nodes > 8
+        om = oracle.OracleScene.from_desc_arrays(*args)
+        co, cd = oracle.camera_rays(96, 64)
+        org2, d2 = _sphere_rays(rng, sph[:, :4][np.isfinite(sph[:, 3])][:12], 60)
+        org2 = np.concatenate([co, org2]); d2 = np.concatenate([cd, d2])
+        assert many.hit(org2, d2).tobytes() == om.hit(org2, d2).tobytes(), variant
+        for method in ("lbvh", "ploc"):  # the device builders place the spheres too
+            many.rebuild_on_device(0, method)
+            assert many.info().bvh_spheres == (64 if variant == "finite" else 63)
+            assert many.hit(org2, d2).tobytes() == om.hit(org2, d2).tobytes(), (variant, method)
+
+
 def test_sphere_only_and_single_triangle_scenes(oracle):
     mat = rt.Opaque((0.5, 0.5, 0.5), 0, 1, 0)
     args = ([_ffi.RT_OBJ_SPHERE], [mat], np.zeros((0, 9)), [], [], [], [], [[0, 0, -3, 1]], [0])

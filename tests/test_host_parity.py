@@ -101,10 +101,31 @@ def test_scene_create_validation():
     assert s.info().bvh_nodes == 0 and s.info().n_spheres == 1
 
 
-def _check_tree(nodes, order, n_tris, tv, depth_reported):
-    """Every triangle is in exactly one leaf; every child box contains its subtree's triangles."""
+def _tree_contents(scene):
+    """What the scene's tree is built over: (ids, vertices). Ids 0 .. n_triangles - 1 are the flat
+    triangles; n_triangles + i is the place of sphere i, found like a triangle's from three
+    vertices (two opposite corners of the sphere's box and its centre). vertices is indexed by id
+    and covers every sphere; ids lists what must sit in the tree (the first 64 finite spheres)."""
+    tv = scene.export_flat()[0]
+    _, _, sph, _ = scene.export_objects()
+    r = np.abs(sph[:, 3:4])
+    places = np.stack([sph[:, :3] - r, sph[:, :3] + r, sph[:, :3]], axis=1).reshape(-1, 3, 3)
+    in_tree = [i for i in range(min(len(sph), 64)) if np.all(np.isfinite(sph[i]))]
+    if scene.info().bvh_spheres == 0:  # a scene of fewer than nine spheres: every ray tests them all
+        in_tree = []
+    assert scene.info().bvh_spheres == len(in_tree)
+    return list(range(len(tv))) + [len(tv) + i for i in in_tree], np.concatenate([tv.reshape(-1, 3, 3), places])
+
+
+def _check_tree(nodes, order, ids, tv, depth_reported):
+    """Everything the tree is built over is in exactly one leaf; every child box contains what
+    lies below it. ids, tv: see _tree_contents (or plain triangles: a count and their vertices)."""
+    if isinstance(ids, (int, np.integer)):
+        ids = list(range(int(ids)))
+    assert sorted(np.asarray(order).tolist()) == sorted(ids)
+    n_tris = len(ids)
     f = nodes.view(np.float32)
-    seen = np.zeros(n_tris, np.int32)
+    seen = np.zeros(len(tv), np.int32)
     max_depth = 0
 
     def walk(ref, depth):
@@ -132,19 +153,65 @@ def _check_tree(nodes, order, n_tris, tv, depth_reported):
     root = 0 if len(nodes) else (~((0 << 2) | (n_tris - 1)) if n_tris else None)
     if root is not None:
         walk(root, 0)
-    assert np.all(seen == 1)
+    assert np.all(seen[ids] == 1) and seen.sum() == len(ids)
     assert max_depth == depth_reported
+
+
+def test_tree_invariants_with_the_six_spheres_placed(monkeypatch, oracle):
+    monkeypatch.setenv("RT_SPHERE_TREE_FROM", "1")
+    s = scenes.build("spot")
+    i = s.info()
+    assert i.bvh_spheres == 6
+    nodes, order = s.export_bvh()
+    ids, tv = _tree_contents(s)
+    _check_tree(nodes, order, ids, tv, i.bvh_depth)
+    co, cd = oracle.camera_rays(96, 72)
+    o = oracle.OracleScene.build("spot")
+    got, _ = o.bvh_hit(nodes, order, 0, co, cd)
+    assert got.tobytes() == o.hit(co, cd, oracle.HIT_BRUTE).tobytes()
 
 
 @pytest.mark.parametrize("name", ["spot", "sphere_floor"])
 def test_tree_invariants(name):
     s = scenes.build(name)
     nodes, order = s.export_bvh()
-    tv = s.export_flat()[0]
     i = s.info()
-    assert sorted(order.tolist()) == list(range(i.n_triangles))
+    ids, tv = _tree_contents(s)
+    assert i.bvh_spheres == 0
     assert i.bvh_depth <= 62
-    _check_tree(nodes, order, i.n_triangles, tv, i.bvh_depth)
+    _check_tree(nodes, order, ids, tv, i.bvh_depth)
+
+
+def test_spheres_have_places_in_the_tree(oracle):
+    """The tree culls spheres like triangles: the first 64 finite spheres each sit in one leaf, by
+    their boxes; a ray tests the spheres whose place it reached and those without a place. The
+    CPU restatement of that traversal equals the exhaustive test of every sphere (src/main.rs:802-810)."""
+    rng = np.random.default_rng(31)
+    k = 72
+    cen = rng.normal(size=(k, 3)) * 2.0 + np.array([0.0, 0.0, -6.0])
+    sph = np.concatenate([cen, rng.uniform(0.1, 0.6, size=(k, 1))], axis=1)
+    sph[7, 3] = -sph[7, 3]  # a negative radius is a sphere like any other (only r * r enters, src/main.rs:247)
+    sph[9, 0] = np.nan      # no place for this one: it is tested (and missed) by every ray
+    mat = rt.Opaque((0.5, 0.5, 0.5), 0, 1, 0)
+    tv = np.array([[[-30, -3, -30], [30, -3, -30], [0, -3, 5]]], dtype=np.float64)
+    tn = np.tile(np.array([0, 1.0, 0]), (1, 3, 1)); tuv = np.zeros((1, 3, 2))
+    args = ([_ffi.RT_OBJ_MESH] + [_ffi.RT_OBJ_SPHERE] * k, [mat] * (k + 1), tv, tn, tuv, [0], [0], sph, list(range(1, k + 1)))
+    s = rt.Scene.from_desc(*args)
+    o = oracle.OracleScene.from_desc_arrays(*args)
+    i = s.info()
+    assert i.bvh_spheres == 63 and i.n_spheres == k
+    nodes, order = s.export_bvh()
+    ids, verts = _tree_contents(s)
+    assert 1 + 9 not in ids and 1 + 64 not in ids and 1 + 7 in ids
+    _check_tree(nodes, order, ids, verts, i.bvh_depth)
+    co, cd = oracle.camera_rays(120, 90)
+    ro = rng.normal(size=(4000, 3)) * 3.0 + np.array([0.0, 0.0, -6.0]); rd = rng.normal(size=(4000, 3))
+    org = np.concatenate([co, ro]); d = np.concatenate([cd, rd])
+    want = o.hit(org, d, oracle.HIT_BRUTE)
+    got, (n_node, n_tri) = o.bvh_hit(nodes, order, 0 if i.bvh_nodes else int(~np.int32(i.n_triangles + i.bvh_spheres - 1)), org, d)
+    assert got.tobytes() == want.tobytes()
+    assert np.count_nonzero(want["tri"] == -1) > 2000
+    assert n_tri / len(org) < 12  # places visited per ray: far fewer than the 72 tests of the exhaustive loop
 
 
 def _adversarial_rays(rng, tv, n):

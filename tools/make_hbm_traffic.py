@@ -25,7 +25,8 @@ out["_doc"] = (
     "Per workload (bench.py --workload) and kernel, means over every launch in rocprofv3 PMC passes of bench.py (separate --pmc FETCH_SIZE, "
     "--pmc WRITE_SIZE and SQ runs, profiles/run_profile.sh): bytes_per_launch = HBM bytes, FETCH_SIZE doubled for the gfx950 "
     "under-count of wide reads, both counters in KiB; valu_wave_insts_per_launch = SQ_INSTS_VALU; valu_lane_use = "
-    "SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU). Launches of one stage (k_wave<false,S,*>) are one entry. _sources names the "
+    "SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU); tcc_requests_per_launch = TCC_HIT_sum + TCC_MISS_sum (requests the L2s received), "
+    "tcp_accesses_per_launch = TCP_TOTAL_CACHE_ACCESSES_sum (accesses of the CUs' vector L1s), valu_insts_per_wave = SQ_INSTS_VALU / SQ_WAVES. Launches of one stage (k_wave<false,S,*>) are one entry. _sources names the "
     "summary each workload was taken from, _library_digests the source digest (rt_source_digest) of the library each was taken on, "
     "_library_revision git's HEAD when this file was last written."
 )
@@ -36,22 +37,28 @@ if len(sys.argv) > 3:
 else:
     out["_library_revision"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=root, capture_output=True, text=True).stdout.strip()
 need = ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU")
+extra = ("TCC_HIT_sum", "TCC_MISS_sum", "TCP_TOTAL_CACHE_ACCESSES_sum", "SQ_WAVES", "SQ_INSTS_VMEM_RD")  # taken along when the passes hold them
 merged = {}
 for name, c in pmc.items():
-    if not name.startswith("k_") or "<true" in name or any(k not in c for k in need):
+    if not isinstance(c, dict) or not name.startswith("k_") or "<true" in name or any(k not in c for k in need):
         continue
-    key = re.sub(r"^(k_wave<false,\d+),(?:false|true)>", r"\1>", name.replace(", ", ","))
+    # k_wave<COUNT, STAGE, LOOP, QUANT>: the launches of one stage are one entry, whichever nodes they walk
+    flat_name = name.replace(" ", "")
+    mw = re.match(r"^(k_wave<false,\d+),(false|true)(?:,(?:false|true))?>$", flat_name)
+    key = mw.group(1) + ">" if mw else flat_name
     # the looping variant is queued behind the plain one as part of the same logged launch: its
     # counts are added, the number of launches is the plain variant's
-    looping = name.replace(" ", "").endswith(",true>")
-    m = merged.setdefault(key, {k: {"launches": 0, "sum": 0.0} for k in need})
-    for k in need:
+    looping = bool(mw) and mw.group(2) == "true"
+    m = merged.setdefault(key, {k: {"launches": 0, "sum": 0.0} for k in need + extra})
+    for k in need + extra:
+        if k not in c:
+            continue
         if not looping:
             m[k]["launches"] += c[k]["launches"]
         m[k]["sum"] += c[k]["sum"]
 w = {}
 for key, c in merged.items():
-    for k in need:
+    for k in need + extra:
         c[k]["per_launch"] = c[k]["sum"] / max(1, c[k]["launches"])
     w[key] = {
         "launches_profiled": c["FETCH_SIZE"]["launches"],
@@ -61,6 +68,15 @@ for key, c in merged.items():
         "valu_wave_insts_per_launch": c["SQ_INSTS_VALU"]["per_launch"],
         "valu_lane_use": round(c["SQ_THREAD_CYCLES_VALU"]["per_launch"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]["per_launch"]), 4),
     }
+    if c["TCC_HIT_sum"]["launches"] and c["TCC_MISS_sum"]["launches"]:
+        req = c["TCC_HIT_sum"]["per_launch"] + c["TCC_MISS_sum"]["per_launch"]
+        w[key]["tcc_requests_per_launch"] = req
+        w[key]["tcc_hit_rate"] = round(c["TCC_HIT_sum"]["per_launch"] / max(1.0, req), 4)
+    if c["TCP_TOTAL_CACHE_ACCESSES_sum"]["launches"]:
+        w[key]["tcp_accesses_per_launch"] = c["TCP_TOTAL_CACHE_ACCESSES_sum"]["per_launch"]
+    if c["SQ_WAVES"]["launches"]:
+        w[key]["waves_per_launch"] = c["SQ_WAVES"]["per_launch"]
+        w[key]["valu_insts_per_wave"] = round(c["SQ_INSTS_VALU"]["per_launch"] / max(1.0, c["SQ_WAVES"]["per_launch"]), 1)
 out[workload] = w
 json.dump(out, open(dst, "w"), indent=1)
 for k, v in w.items():

@@ -30,6 +30,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -65,7 +66,7 @@ struct LogRec {
   uint32_t n_hit, n_ray;        // queue records counted by this plan
   uint32_t overflow;            // some segment holds more records than it has room for (never, by construction)
   uint32_t hit_blocks, ray_blocks;  // as in the plan
-  uint32_t pad;
+  uint32_t stamp;                   // written last: the low 32 bits of the snapshot's sequence number, plus one
 };
 #define RT_PLAN_RECS 4 /* PlanRec per plan slot: [0] the launch, [1] only if it fits `split_at`, [2] only if not */
 #define RT_PLAN_SLOTS 4096  /* ring of plans and counter snapshots; harvested long before it wraps */
@@ -108,10 +109,25 @@ struct DeviceScene {
   // How many bounce launches a frame of a given shape needed before its queue was down to the
   // tail threshold: learnt on the first such frame (the host watches the counts), then reused, so
   // that later frames are queued without the host waiting for anything.
-  uint64_t hist_key = 0;
-  uint32_t hist_rounds = 0;
-  std::vector<uint32_t> hist_blocks;  // record blocks per segment of bounce launch 0 .. hist_rounds - 1, then of the tail
-  bool hist_valid = false;
+  struct Hist {
+    uint64_t key = 0;
+    uint32_t rounds = 0;
+    std::vector<uint32_t> blocks;  // record blocks per segment of bounce launch 0 .. rounds - 1, then of the tail
+    uint64_t used = 0;             // hist_clock when last looked up: the least recently used shape makes room
+  };
+  std::vector<Hist> hists;         // a few shapes (a call in several sample chunks alone has two)
+  uint64_t hist_clock = 0;
+  // What a frame queued, kept until its plans have landed in host memory: the history of its shape is
+  // made (or refined) from them then — by a later call, or by whoever waits for the scene next —
+  // without the frame itself ever waiting.
+  struct FrameLearn {
+    uint64_t key;
+    std::vector<int64_t> round_plans;  // snapshot that sized bounce launch r
+    int64_t final_plan;                // snapshot after the last bounce launch: what the tail was handed
+    uint32_t seg_blocks, threshold;
+    bool handoff;
+  };
+  std::deque<FrameLearn> learn_q;
   // Overlapped tails: when a call runs in several sample chunks, the thin tail of long paths of
   // one chunk (and that chunk's resolve) runs on a side stream while the next chunk starts.
   hipStream_t side = nullptr;
@@ -478,6 +494,82 @@ static int harvest_timing(DeviceScene* d) {
   return RT_OK;
 }
 
+// Bounce launches a frame of n_paths paths is given when nothing is known about its shape: the queue
+// after the first stage holds about a quarter of the paths and loses about a quarter per bounce
+// (measured on the reference's scenes: 0.5 to 0.8 survive a bounce, the later the more).
+static uint32_t guess_rounds(uint64_t n_records, uint32_t threshold) {
+  uint32_t r = 0;
+  double n = (double)n_records;
+  while (n > (double)threshold && r < 48u) {
+    n *= 0.75;
+    ++r;
+  }
+  return r;
+}
+
+static const LogRec* landed_plan(const DeviceScene* d, int64_t seq) {
+  if (seq < 0 || d->snap_seq - (uint64_t)seq > RT_PLAN_SLOTS) return nullptr;  // its slot of the ring has been reused
+  const LogRec* lr = d->host_log + ((uint64_t)seq % RT_PLAN_SLOTS);
+  if (*reinterpret_cast<const volatile uint32_t*>(&lr->stamp) != (uint32_t)((uint64_t)seq + 1u)) return nullptr;
+  return lr;
+}
+
+// Makes (or refines) the history of the shapes whose frames' plans have all arrived in host memory,
+// oldest frame first; stops at the first frame still in flight. Never waits.
+static void learn_from_landed_frames(DeviceScene* d) {
+  while (!d->learn_q.empty()) {
+    const DeviceScene::FrameLearn& fl = d->learn_q.front();
+    const bool lost = fl.final_plan < 0 || d->snap_seq - (uint64_t)fl.final_plan > RT_PLAN_SLOTS;
+    const LogRec* last = lost ? nullptr : landed_plan(d, fl.final_plan);
+    if (!lost && !last) return;  // still in flight (the plans of a stream land in order)
+    if (last) {
+      DeviceScene::Hist h;
+      h.key = fl.key;
+      bool complete = true;
+      uint32_t tail_blocks = last->hit_blocks + last->ray_blocks;
+      bool below = false;
+      for (size_t r = 0; r < fl.round_plans.size() && complete; ++r) {
+        const LogRec* lr = landed_plan(d, fl.round_plans[r]);
+        if (!lr) {
+          complete = false;
+          break;
+        }
+        if ((uint64_t)lr->n_hit + lr->n_ray <= fl.threshold) {  // the tail takes over from here
+          tail_blocks = lr->hit_blocks + lr->ray_blocks;
+          below = true;
+          break;
+        }
+        h.blocks.push_back(lr->hit_blocks + lr->ray_blocks);
+      }
+      if (complete) {
+        if (!below) {
+          // the launches queued did not bring the queue down to the threshold: more of them next time,
+          // sized like the last one (queues only shrink)
+          const uint32_t more = guess_rounds((uint64_t)last->n_hit + last->n_ray, fl.threshold);
+          for (uint32_t e = 0; e < more; ++e) h.blocks.push_back(std::min(fl.seg_blocks, tail_blocks));
+        }
+        h.rounds = (uint32_t)h.blocks.size();
+        h.blocks.push_back(fl.handoff ? 0u : tail_blocks);
+        h.used = ++d->hist_clock;
+        DeviceScene::Hist* slot = nullptr;
+        for (DeviceScene::Hist& x : d->hists)
+          if (x.key == h.key) slot = &x;
+        if (!slot && d->hists.size() < 8) {
+          d->hists.emplace_back();
+          slot = &d->hists.back();
+        }
+        if (!slot) {
+          slot = &d->hists[0];
+          for (DeviceScene::Hist& x : d->hists)
+            if (x.used < slot->used) slot = &x;
+        }
+        *slot = std::move(h);
+      }
+    }
+    d->learn_q.pop_front();
+  }
+}
+
 // Fills the launch log entries whose work is the difference of two counter snapshots (the caller
 // has waited for the streams the snapshots were taken on), then folds the oldest entries of a long
 // run into one entry per kind so that the log stays bounded.
@@ -503,6 +595,8 @@ static int harvest_accounts(DeviceScene* d) {
     overflow = overflow || after.overflow != 0;
   }
   d->accounts.clear();
+  learn_from_landed_frames(d);  // everything queued has finished: every frame's plans are there
+  d->learn_q.clear();
   if (d->last_main_snap >= 0) {
     std::memcpy(d->base_main, d->host_log[(uint64_t)d->last_main_snap % RT_PLAN_SLOTS].w, sizeof d->base_main);
     d->last_main_snap = -2;
@@ -973,7 +1067,7 @@ __device__ __forceinline__ uint32_t wave_reserve(unsigned long long* word, unsig
 #define RT_PLAN_THREADS 256
 __global__ __launch_bounds__(RT_PLAN_THREADS) void k_plan(unsigned long long* counters, uint32_t in_hit_word, uint32_t in_ray_word, int zero_word,
                                                           uint32_t n_seg, uint32_t seg_cap, uint32_t split_at, PlanRec* __restrict__ plan,
-                                                          LogRec* __restrict__ log) {
+                                                          LogRec* __restrict__ log, uint32_t stamp) {
   // Thread t reads words 2p, 2p + 1 (p = t % 8) of lines t / 8, t / 8 + 32, ...: eight threads share
   // a line, every load instruction of a wave covers eight whole lines, the 32 loads of a thread do
   // not depend on each other, and the two counts of a queue (adjacent words, the first one even)
@@ -1030,7 +1124,10 @@ __global__ __launch_bounds__(RT_PLAN_THREADS) void k_plan(unsigned long long* co
     }
     s_sum[0][t] = x;
     s_max[0][t] = m;
-    if (log && t < CNT_N) log->w[t] = x;
+    if (log && t < CNT_N) {
+      log->w[t] = x;
+      __threadfence_system();  // in host memory before the stamp below says the record is complete
+    }
   }
   __syncthreads();
   if (t == 0) {
@@ -1054,7 +1151,8 @@ __global__ __launch_bounds__(RT_PLAN_THREADS) void k_plan(unsigned long long* co
       log->overflow = over;
       log->hit_blocks = pr.hit_blocks;
       log->ray_blocks = pr.ray_blocks;
-      log->pad = 0;
+      __threadfence_system();
+      *reinterpret_cast<volatile uint32_t*>(&log->stamp) = stamp;  // the host reads a record only when its stamp matches
     }
   }
 }
@@ -1677,7 +1775,7 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
     }
     *seq = (int64_t)d->snap_seq++;
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(RT_PLAN_THREADS), 0, on, lines, in_hit_word, in_ray_word, zero_word, n_seg, seg_cap, split_at,
-                       plan_at(*seq), d->host_log + ((uint64_t)*seq % RT_PLAN_SLOTS));
+                       plan_at(*seq), d->host_log + ((uint64_t)*seq % RT_PLAN_SLOTS), (uint32_t)((uint64_t)*seq + 1u));
     HIP_TRY(hipGetLastError());
     return RT_OK;
   };
@@ -1758,28 +1856,48 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
                          (uint64_t)p->tile_size, (uint64_t)p->tile_rank, (uint64_t)p->tile_ranks, (uint64_t)fuse_bounces, (uint64_t)long_steps,
                          (uint64_t)tail_threshold, (uint64_t)(p->flags & RT_FLAG_NO_JITTER)})
         key = (key ^ v) * 0x100000001b3ull;
-      const bool learnt = !always_watch && d->hist_valid && d->hist_key == key;
-      std::vector<uint32_t> seen;  // record blocks per segment, launch by launch (a frame of a new shape)
-      // Grid of the plain form of launch `r` over a queue: exactly what the plan says when the host
-      // has read it, else what the frame this shape was learnt on needed plus an eighth; the
-      // looping form behind it covers the rest, if there is any.
+      // Three ways to size them. A shape seen before (`known`): as many launches as its last frame
+      // needed, grids of what those needed plus an eighth, the looping form behind each for the
+      // rest. A new shape: a guessed number of launches, each in the looping form alone, which covers
+      // a queue of any length (slower: it holds more registers and fewer workgroups; it is one
+      // frame). Either way the host waits for nothing, and the plans the frame leaves behind in host
+      // memory become the shape's history as soon as they are all there. RT_SYNC_ROUNDS=1: the
+      // host reads every plan before the launch it sizes (exact grids; a wait per bounce).
+      learn_from_landed_frames(d);
+      const DeviceScene::Hist* known = nullptr;
+      if (!always_watch)
+        for (DeviceScene::Hist& x : d->hists)
+          if (x.key == key) {
+            x.used = ++d->hist_clock;
+            known = &x;
+          }
+      const uint32_t blind_rounds = guess_rounds(pp.n_paths / 4u, tail_threshold);
+      DeviceScene::FrameLearn fl;
+      fl.key = key;
+      fl.final_plan = -1;
+      fl.seg_blocks = seg_cap / RT_BLOCK;
+      fl.threshold = tail_threshold;
+      fl.handoff = handoff;
+      // Grid of the plain form of launch `r` over a queue, and whether the looping form must follow
+      // it to cover what that grid may have missed.
       auto sized_grid = [&](uint32_t r, int64_t plan_seq, uint32_t* gy) -> bool {
-        if (!learnt) {
+        if (always_watch) {  // the host has read the plan: exact, nothing left to cover
           const LogRec& lr = d->host_log[(uint64_t)plan_seq % RT_PLAN_SLOTS];
           *gy = lr.hit_blocks + lr.ray_blocks;
-          seen.push_back(*gy);
-          return false;  // exact: nothing left to cover
+          return false;
         }
-        const uint32_t h = r < d->hist_blocks.size() ? d->hist_blocks[r] : 0u;
+        if (!known) {  // the looping form alone
+          *gy = 0u;
+          return true;
+        }
+        const uint32_t h = r < known->blocks.size() ? known->blocks[r] : 0u;
         *gy = std::min<uint32_t>(seg_blocks, h + h / 8u + 2u);
         return *gy < seg_blocks;
       };
       uint32_t rounds = 0;
       int cur = 0;
       for (;;) {
-        if (learnt) {
-          if (rounds >= d->hist_rounds) break;
-        } else {
+        if (always_watch) {
           HIP_TRY(hipStreamSynchronize(stream));
           const LogRec& lr = d->host_log[(uint64_t)snap % RT_PLAN_SLOTS];
           if (lr.overflow || (uint64_t)lr.n_hit + lr.n_ray > pp.n_paths) {
@@ -1787,6 +1905,8 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
             return RT_ERR_HIP;
           }
           if ((uint64_t)lr.n_hit + lr.n_ray <= tail_threshold) break;
+        } else if (rounds >= (known ? known->rounds : blind_rounds)) {
+          break;
         }
         const int nxt = cur ^ 1;
         uint32_t gy = 0;
@@ -1796,11 +1916,17 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
         if (cover) launch_wave<1>(count, true, d->grid_ok, cgrid, lds, stream, d->k, pp, qv[cur], qv[nxt], n_seg, plan_at(snap), gy, samples, counters);
         if ((rc = end_launch(stream)) != RT_OK) return rc;
         const int64_t sized_by = snap;
+        fl.round_plans.push_back(sized_by);
         // counts of the queue just written; the counts of the one just read start the next round at zero
         if ((rc = take_plan(stream, counters, qv[nxt].hit_word, qv[nxt].ray_word, (int)qv[cur].hit_word, n_seg, seg_cap, split_at, &snap)) != RT_OK) return rc;
         account_main(snap, sized_by);
         cur = nxt;
         rounds++;
+      }
+      fl.final_plan = snap;
+      if (!always_watch) {
+        if (d->learn_q.size() >= 64) d->learn_q.pop_front();
+        d->learn_q.push_back(std::move(fl));
       }
       const int nxt = cur ^ 1;
 
@@ -1833,9 +1959,8 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
         d->accounts.push_back(DeviceScene::Account{d->launches.size() - 1, tplan, tafter, tplan});
         d->last_tail_snap = tafter;
         resolve_on = d->side;
-        if (!learnt) seen.push_back(0u);
       } else {
-        if (!learnt) HIP_TRY(hipStreamSynchronize(stream));  // the last plan may not have been read yet
+        if (always_watch) HIP_TRY(hipStreamSynchronize(stream));  // the last plan may not have been read yet
         uint32_t gy = 0;
         const bool cover = sized_grid(rounds, snap, &gy);
         if ((rc = begin_launch(2, 0u, stream)) != RT_OK) return rc;
@@ -1845,12 +1970,6 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
         const int64_t sized_by = snap;
         if ((rc = take_plan(stream, counters, CNT_Q0, CNT_R0, -1, 0u, 0u, 0u, &snap)) != RT_OK) return rc;
         account_main(snap, sized_by);
-      }
-      if (!learnt) {
-        d->hist_key = key;
-        d->hist_rounds = rounds;
-        d->hist_blocks.swap(seen);
-        d->hist_valid = true;
       }
     }
     // The running per-pixel totals pass from chunk to chunk in order: a handed-off chunk resolves

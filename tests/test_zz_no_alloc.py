@@ -101,3 +101,42 @@ def test_rejects_what_does_not_fit_and_scenes_not_uploaded():
     spot.render_device_noalloc(big.data_ptr(), rt.render_params(width=1280, height=720, spp=1), 0)
     torch.cuda.synchronize()
     assert float(big.sum()) > 0.0
+
+
+def test_a_frame_captured_into_a_graph_replays_the_same_bits():
+    """The allocation-free call under HIP graph capture (what it exists for): it makes no waiting
+    call, whether the frame's shape has been seen before or not, so a frame can be captured on the
+    caller's stream and replayed. Every replay adds the same frame to the canvas, bit for bit what
+    rt_render_device adds."""
+    spot = _scene("spot")
+    side = torch.cuda.Stream()
+    for shape, (w, h, spp) in {"a shape never rendered before": (136, 88, 3), "a shape rendered before": (160, 120, 4)}.items():
+        p = rt.render_params(width=w, height=h, spp=spp, seed=11)
+        want = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
+        got = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
+        with torch.cuda.stream(side):
+            stream = side.cuda_stream
+            # the scene's last call must have been on the capturing stream (a call on another stream
+            # starts behind an event of the previous one, which a capture cannot wait for)
+            warm = rt.render_params(width=32, height=24, spp=1, seed=1)
+            spot.render_device(want.data_ptr(), warm, stream)
+            if shape == "a shape rendered before":
+                spot.render_device(want.data_ptr(), p, stream)
+            spot.wait()
+            want.zero_()
+            for _ in range(2):
+                spot.render_device(want.data_ptr(), p, stream)
+            spot.wait()
+            rays = spot.last_stats().rays
+            side.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                spot.render_device_noalloc(got.data_ptr(), p, torch.cuda.current_stream().cuda_stream)
+            side.synchronize()
+            assert float(got.abs().sum()) == 0.0, "capture must not run the frame"
+            g.replay()
+            g.replay()
+            side.synchronize()
+        torch.cuda.synchronize()
+        assert got.cpu().numpy().tobytes() == want.cpu().numpy().tobytes(), shape
+        assert spot.last_stats().rays == rays, shape

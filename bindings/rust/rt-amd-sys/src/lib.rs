@@ -223,7 +223,8 @@ extern "C" {
     pub fn rt_group_destroy(group: *mut rt_group);
     pub fn rt_group_size(group: *const rt_group, n_members: *mut u32) -> c_int;
     pub fn rt_group_render_accumulate(group: *mut rt_group, p: *const rt_render_params, split: u32, canvas: *mut f64, rays_out: *mut u64) -> c_int;
-    pub fn rt_group_render_device(group: *mut rt_group, p: *const rt_render_params, split: u32, device_canvas: *mut f64, rays_out: *mut u64) -> c_int;
+    pub fn rt_group_render_device(group: *mut rt_group, p: *const rt_render_params, split: u32, device_canvas: *mut f64, stream: *mut c_void) -> c_int;
+    pub fn rt_group_wait(group: *mut rt_group, rays_out: *mut u64) -> c_int;
     pub fn rt_group_member_info(group: *const rt_group, member: u32, device: *mut c_int, rays: *mut u64, ms: *mut f64) -> c_int;
     pub fn rt_scene_last_stats(scene: *mut rt_scene, out: *mut rt_stats) -> c_int;
     pub fn rt_scene_last_timing(scene: *mut rt_scene, out: *mut rt_timing) -> c_int;

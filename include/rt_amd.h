@@ -424,19 +424,28 @@ int rt_group_size(const rt_group* group, uint32_t* n_members);
 /* render::<W,H> over the group, src/main.rs:977-1039: canvas[v][u][c] += mean over p->spp
  * samples, canvas a host buffer as for rt_render_accumulate. p describes the whole frame:
  * tile_rank/tile_ranks must be zero, tile_size is the tile edge of RT_SPLIT_TILES (0: 64),
- * RT_FLAG_PIPELINE is ignored. Every member's sum of samples is rounded to binary32 once per
- * pixel before the members are added in binary64, so a frame agrees with a single GPU's to
- * about 1e-7 relative, not bit for bit. Returns when the canvas is complete. */
+ * RT_FLAG_PIPELINE and RT_FLAG_TIMING are ignored. Every member's sum of samples is rounded to
+ * binary32 once per pixel before the members are added in binary64, so a frame agrees with a
+ * single GPU's to about 1e-7 relative, not bit for bit. Returns when the canvas is complete;
+ * rays_out (may be NULL) receives the nearest-hit queries of all members. */
 int rt_group_render_accumulate(rt_group* group, const rt_render_params* p, uint32_t split, double* canvas,
                                uint64_t* rays_out);
-/* Same with the canvas in the memory of the group's first device. The call first waits for
- * everything queued on that device (a clear of the canvas on a stream of the caller's, say), so
- * the combination cannot overtake it. */
-int rt_group_render_device(rt_group* group, const rt_render_params* p, uint32_t split, double* device_canvas,
-                           uint64_t* rays_out);
-/* What member `member` did in the last frame: its device, the nearest-hit queries it answered
- * and the time its share took on its GPU (between two events on the member's stream) — the load
- * balance of the split. */
+/* Same with the canvas in the memory of the group's first device, as part of a frame loop: the
+ * call only queues work and returns. `stream` (a hipStream_t of the first device, NULL for its
+ * default stream) orders the canvas: the frame is added behind everything the stream held when the
+ * call was made (a clear of the canvas, the previous frame), and whatever is queued on the stream
+ * afterwards sees the frame in the canvas. Nothing else on the device is waited for. Every member
+ * keeps two sum buffers, so the members render frame k + 1 while the first device still combines
+ * frame k. rt_group_wait collects a run of such calls. */
+int rt_group_render_device(rt_group* group, const rt_render_params* p, uint32_t split, double* device_canvas, void* stream);
+/* Waits for every frame queued so far. rays_out (may be NULL) receives the nearest-hit queries
+ * all members answered in the frames since the previous rt_group_wait (or the group's creation).
+ * RT_ERR_INVALID if one of those frames could not be queued completely (its call said so too). */
+int rt_group_wait(rt_group* group, uint64_t* rays_out);
+/* What member `member` did in the frames the latest rt_group_wait (or rt_group_render_accumulate)
+ * covered: its device, the nearest-hit queries it answered in them, and the time its share of the
+ * latest of them took on its GPU (between two events on the member's stream) — the load balance
+ * of the split. */
 int rt_group_member_info(const rt_group* group, uint32_t member, int* device, uint64_t* rays, double* ms);
 
 /* impl Into<Rgba<u8>> for RGBA, src/main.rs:29-37, applied to canvas / its as the display loop

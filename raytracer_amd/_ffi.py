@@ -207,7 +207,8 @@ SIGNATURES = {
     "rt_group_destroy": (None, [_P]),
     "rt_group_size": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
     "rt_group_render_accumulate": (C.c_int, [_P, C.POINTER(rt_render_params), C.c_uint32, _P, C.POINTER(C.c_uint64)]),
-    "rt_group_render_device": (C.c_int, [_P, C.POINTER(rt_render_params), C.c_uint32, _P, C.POINTER(C.c_uint64)]),
+    "rt_group_render_device": (C.c_int, [_P, C.POINTER(rt_render_params), C.c_uint32, _P, _P]),
+    "rt_group_wait": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "rt_group_member_info": (C.c_int, [_P, C.c_uint32, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
     "rt_scene_last_stats": (C.c_int, [_P, C.POINTER(rt_stats)]),
     "rt_scene_last_timing": (C.c_int, [_P, C.POINTER(rt_timing)]),

@@ -6,7 +6,10 @@
 // copy of the read-only scene in its own HBM and its own stream. A render call only queues work
 // (its launch extents are decided on the device), so the calling thread queues every member's
 // share one after the other and the GPUs run them side by side; events, not host threads, order
-// the combination behind the members.
+// the combination behind the members. Nothing in a frame waits on the host: the combination is
+// ordered behind the caller's stream and behind the members by events, every member has two sum
+// buffers, so a member renders frame k + 1 while the first GPU still combines frame k, and the
+// caller collects a run of frames with rt_group_wait.
 //
 // Exchange step. Every member leaves a binary32 [H][W][3] sum of its samples in its own HBM.
 // The GPUs of a node are fully connected by xGMI links, so instead of a ring the first member's
@@ -64,18 +67,28 @@ struct Member {
   rt_scene view;  // no host arrays: only the device half, uploaded from the caller's scene
   int device = -1;
   hipStream_t stream = nullptr;
-  hipEvent_t ev_begin = nullptr, ev_end = nullptr;  // around the member's share of a frame, on its stream
-  float* sum = nullptr;
-  size_t sum_bytes = 0;
-  // last frame
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr;  // around the member's share of the latest frame, on its stream
+  float* sum[2] = {nullptr, nullptr};               // frame k is summed into sum[k & 1]
+  size_t sum_bytes[2] = {0, 0};
+  bool timed = false;  // ev_begin / ev_end have been recorded since the last rt_group_wait
+  // the frames covered by the latest rt_group_wait
   uint64_t rays = 0;
-  double ms = 0.0;
+  double ms = 0.0;     // of the latest of them
 };
 
 }  // namespace
 
 struct rt_group {
   std::vector<std::unique_ptr<Member>> members;
+  // on the first device: the stream the frames are combined on, and per sum-buffer parity the event
+  // of the caller's stream a frame starts behind and the event of its combination (which the
+  // caller's stream, and the members' next use of that buffer, wait for)
+  hipStream_t combine = nullptr;
+  hipStream_t own = nullptr;  // the caller's stream of the host-buffer entry point
+  hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_combined[2] = {nullptr, nullptr};
+  bool combined_valid[2] = {false, false};
+  uint64_t frames = 0;  // queued so far
+  std::string failed;   // a frame that failed half queued: reported by the next rt_group_wait
   double* stage = nullptr;  // frame of the host-buffer entry point, on the first device
   size_t stage_bytes = 0;
   void* host_stage = nullptr;  // the same frame in pinned host memory
@@ -89,14 +102,21 @@ static void group_free(rt_group* g) {
     (void)hipSetDevice(m->device);
     if (m->view.dev) rt_device_scene_free(m->view.dev);
     m->view.dev = nullptr;
-    if (m->sum) (void)hipFree(m->sum);
+    for (int b = 0; b < 2; ++b)
+      if (m->sum[b]) (void)hipFree(m->sum[b]);
     if (m->ev_begin) (void)hipEventDestroy(m->ev_begin);
     if (m->ev_end) (void)hipEventDestroy(m->ev_end);
     if (m->stream) (void)hipStreamDestroy(m->stream);
   }
-  if (g->stage && !g->members.empty()) {
+  if (!g->members.empty() && g->members[0] && g->members[0]->device >= 0) {
     (void)hipSetDevice(g->members[0]->device);
-    (void)hipFree(g->stage);
+    if (g->stage) (void)hipFree(g->stage);
+    for (int b = 0; b < 2; ++b) {
+      if (g->ev_in[b]) (void)hipEventDestroy(g->ev_in[b]);
+      if (g->ev_combined[b]) (void)hipEventDestroy(g->ev_combined[b]);
+    }
+    if (g->combine) (void)hipStreamDestroy(g->combine);
+    if (g->own) (void)hipStreamDestroy(g->own);
   }
   if (g->host_stage) (void)hipHostFree(g->host_stage);
   delete g;
@@ -176,6 +196,16 @@ static int rt_group_create_body(const rt_scene* scene, const int* devices, uint3
       return rc;
     }
   }
+  HIP_TRY(hipSetDevice(root));
+  bool ok = hipStreamCreateWithFlags(&g->combine, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&g->own, hipStreamNonBlocking) == hipSuccess;
+  for (int b = 0; b < 2 && ok; ++b)
+    ok = hipEventCreateWithFlags(&g->ev_in[b], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&g->ev_combined[b], hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
+    rt_set_error("rt_group_create: hipStreamCreate / hipEventCreate on device %d failed", root);
+    group_free(g);
+    return RT_ERR_HIP;
+  }
   *out = g;
   return RT_OK;
 }
@@ -207,8 +237,10 @@ extern "C" int rt_group_member_info(const rt_group* group, uint32_t member, int*
   return RT_OK;
 }
 
-static int group_render(rt_group* g, const rt_render_params* p, uint32_t split, double* device_canvas, uint64_t* rays_out,
-                        const char* who) {
+// Queues one frame: every member's share on that member's stream, the combination on the first
+// device behind them and behind what `stream` held when the call was made; `stream` in turn waits
+// for the combination. Returns without waiting for any of it.
+static int group_queue_frame(rt_group* g, const rt_render_params* p, uint32_t split, double* device_canvas, hipStream_t stream, const char* who) {
   if (!g || !p || !device_canvas) {
     rt_set_error("%s: null argument", who);
     return RT_ERR_INVALID;
@@ -225,6 +257,10 @@ static int group_render(rt_group* g, const rt_render_params* p, uint32_t split, 
     rt_set_error("%s: bad image size %ux%u", who, p->width, p->height);
     return RT_ERR_INVALID;
   }
+  if (p->max_depth < 0 || p->max_depth > 100000 || !(p->fov_y_deg > 0.0 && p->fov_y_deg < 180.0) || !(p->dof_strength >= 0.0)) {
+    rt_set_error("%s: bad max_depth, fov_y_deg or dof_strength", who);  // before anything is queued
+    return RT_ERR_INVALID;
+  }
   const uint32_t n = (uint32_t)g->members.size();
   uint32_t tile = 0;
   if (split == RT_SPLIT_TILES) {
@@ -237,20 +273,20 @@ static int group_render(rt_group* g, const rt_render_params* p, uint32_t split, 
   const uint32_t total = p->spp_total ? p->spp_total : p->spp;
   const uint64_t n_elems = (uint64_t)p->width * p->height * 3u;
   const size_t sum_bytes = (size_t)n_elems * sizeof(float);
+  const int b = (int)(g->frames & 1u);
 
-  // Whatever the caller did to the canvas before this call (a clear on a stream of its own, say)
-  // must be done before the combination adds to it.
+  // Whatever the caller queued on its stream before this call (a clear of the canvas, say) comes
+  // before the combination; nothing else on the device is waited for.
   Member& root = *g->members[0];
   HIP_TRY(hipSetDevice(root.device));
-  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipEventRecord(g->ev_in[b], stream));
 
-  // queue every member's share; each render call returns as soon as its launches are queued (the
-  // first frame of a new shape excepted: there the host watches the queue counts once)
   for (uint32_t i = 0; i < n; ++i) {
     Member& m = *g->members[i];
     rt_render_params mp = *p;
-    mp.flags &= ~RT_FLAG_PIPELINE;
-    mp.flags |= RT_FLAG_STORE;  // the member's buffer takes the frame's sums as they are: no clear
+    // the member's frames form a pipelined run: a frame's thin tail overlaps the member's next frame
+    mp.flags |= RT_FLAG_PIPELINE | RT_FLAG_STORE;  // STORE: the buffer takes the frame's sums as they are, no clear
+    mp.flags &= ~RT_FLAG_TIMING;
     mp.spp_total = total;
     if (split == RT_SPLIT_SAMPLES) {
       const uint32_t lo = (uint32_t)(((uint64_t)p->spp * i) / n), hi = (uint32_t)(((uint64_t)p->spp * (i + 1)) / n);
@@ -263,65 +299,99 @@ static int group_render(rt_group* g, const rt_render_params* p, uint32_t split, 
       mp.tile_ranks = n;
     }
     HIP_TRY(hipSetDevice(m.device));
-    if (m.sum_bytes < sum_bytes) {
-      if (m.sum) (void)hipFree(m.sum);
-      m.sum = nullptr;
-      m.sum_bytes = 0;
-      HIP_TRY(hipMalloc((void**)&m.sum, sum_bytes));
-      m.sum_bytes = sum_bytes;
+    if (m.sum_bytes[b] < sum_bytes) {
+      // growing a buffer: the combination that last read it must be over (a frame of another size
+      // was in flight; rare, and the only wait a frame can meet)
+      if (g->combined_valid[b]) HIP_TRY(hipEventSynchronize(g->ev_combined[b]));
+      if (m.sum[b]) (void)hipFree(m.sum[b]);
+      m.sum[b] = nullptr;
+      m.sum_bytes[b] = 0;
+      HIP_TRY(hipMalloc((void**)&m.sum[b], sum_bytes));
+      m.sum_bytes[b] = sum_bytes;
     }
+    // this buffer was last read by the combination of the frame before the previous one
+    if (g->combined_valid[b]) HIP_TRY(hipStreamWaitEvent(m.stream, g->ev_combined[b], 0));
     HIP_TRY(hipEventRecord(m.ev_begin, m.stream));
     // a member without samples of its own (more members than samples) contributes zeros
-    if (mp.spp == 0 && split == RT_SPLIT_SAMPLES) HIP_TRY(hipMemsetAsync(m.sum, 0, sum_bytes, m.stream));
-    const int rc = rt_render_sum_f32_device(&m.view, &mp, m.sum, m.stream);
+    if (mp.spp == 0 && split == RT_SPLIT_SAMPLES) HIP_TRY(hipMemsetAsync(m.sum[b], 0, sum_bytes, m.stream));
+    int rc = rt_render_sum_f32_device(&m.view, &mp, m.sum[b], m.stream);
+    if (rc == RT_OK) {
+      HIP_TRY(hipEventRecord(m.ev_end, m.stream));
+      m.timed = true;
+      // the combination starts behind everything this member has queued, its own side stream included
+      rc = rt_scene_stream_wait(&m.view, g->combine);
+    }
     if (rc != RT_OK) {
       const std::string why = rt_last_error();
       rt_set_error("%s: member %u (device %d): %s", who, i, m.device, why.c_str());
-      for (uint32_t j = 0; j < i; ++j) {  // let what is already queued run out before reporting
-        (void)hipSetDevice(g->members[j]->device);
-        (void)hipStreamSynchronize(g->members[j]->stream);
-      }
+      g->failed = rt_last_error();  // members before this one have their shares queued: the frame is void
       return rc;
     }
-    HIP_TRY(hipEventRecord(m.ev_end, m.stream));
   }
 
-  // combine on the first device, behind every member's share
+  // combine on the first device, behind the caller's stream and every member's share
   HIP_TRY(hipSetDevice(root.device));
-  for (uint32_t i = 1; i < n; ++i) HIP_TRY(hipStreamWaitEvent(root.stream, g->members[i]->ev_end, 0));
+  HIP_TRY(hipStreamWaitEvent(g->combine, g->ev_in[b], 0));
   SumTable t{};
-  for (uint32_t i = 0; i < n; ++i) t.sum[i] = g->members[i]->sum;
+  for (uint32_t i = 0; i < n; ++i) t.sum[i] = g->members[i]->sum[b];
   // a single member in tile mode owns every tile; n == 1 needs no owner arithmetic either way
   const uint32_t k_tile = (split == RT_SPLIT_TILES && n > 1) ? tile : 0u;
   const uint32_t tiles_x = k_tile ? (p->width + k_tile - 1) / k_tile : 0u;
   const uint64_t blocks = (n_elems + 255u) / 256u;
-  hipLaunchKernelGGL(k_combine, dim3((uint32_t)blocks), dim3(256), 0, root.stream, t, n, n_elems, p->width, k_tile, tiles_x,
+  hipLaunchKernelGGL(k_combine, dim3((uint32_t)blocks), dim3(256), 0, g->combine, t, n, n_elems, p->width, k_tile, tiles_x,
                      (double)total, device_canvas);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(root.stream));
+  HIP_TRY(hipEventRecord(g->ev_combined[b], g->combine));
+  g->combined_valid[b] = true;
+  HIP_TRY(hipStreamWaitEvent(stream, g->ev_combined[b], 0));  // what the caller queues next sees the frame in the canvas
+  g->frames++;
+  return RT_OK;
+}
 
-  // the frame is complete: what each member did
+// Waits for every frame queued so far and collects what the members did in them.
+static int group_wait(rt_group* g, uint64_t* rays_out) {
+  if (!g) {
+    rt_set_error("rt_group_wait: null group");
+    return RT_ERR_INVALID;
+  }
+  Member& root = *g->members[0];
+  HIP_TRY(hipSetDevice(root.device));
+  HIP_TRY(hipStreamSynchronize(g->combine));
   uint64_t rays = 0;
-  for (uint32_t i = 0; i < n; ++i) {
-    Member& m = *g->members[i];
+  for (auto& mp : g->members) {
+    Member& m = *mp;
     HIP_TRY(hipSetDevice(m.device));
     rt_stats st;
-    const int rc = rt_scene_last_stats(&m.view, &st);
-    if (rc != RT_OK) return rc;
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, m.ev_begin, m.ev_end));
-    m.rays = st.rays;
-    m.ms = ms;
+    m.rays = 0;
+    m.ms = 0.0;
+    if (m.view.dev && m.timed) {  // ends the member's run of pipelined frames: the run's totals
+      const int rc = rt_scene_last_stats(&m.view, &st);
+      if (rc != RT_OK) return rc;
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, m.ev_begin, m.ev_end));
+      m.rays = st.rays;
+      m.ms = ms;
+      m.timed = false;
+    }
     rays += m.rays;
   }
   if (rays_out) *rays_out = rays;
   HIP_TRY(hipSetDevice(root.device));
+  if (!g->failed.empty()) {
+    rt_set_error("rt_group_wait: an earlier frame was not queued completely: %s", g->failed.c_str());
+    g->failed.clear();
+    return RT_ERR_INVALID;
+  }
   return RT_OK;
 }
 
-extern "C" int rt_group_render_device(rt_group* group, const rt_render_params* p, uint32_t split, double* device_canvas,
-                                      uint64_t* rays_out) {
-  return rt_guard("rt_group_render_device", [&] { return group_render(group, p, split, device_canvas, rays_out, "rt_group_render_device"); });
+extern "C" int rt_group_render_device(rt_group* group, const rt_render_params* p, uint32_t split, double* device_canvas, void* stream) {
+  return rt_guard("rt_group_render_device",
+                  [&] { return group_queue_frame(group, p, split, device_canvas, (hipStream_t)stream, "rt_group_render_device"); });
+}
+
+extern "C" int rt_group_wait(rt_group* group, uint64_t* rays_out) {
+  return rt_guard("rt_group_wait", [&] { return group_wait(group, rays_out); });
 }
 
 static int rt_group_render_accumulate_body(rt_group* g, const rt_render_params* p, uint32_t split, double* canvas, uint64_t* rays_out) {
@@ -335,6 +405,8 @@ static int rt_group_render_accumulate_body(rt_group* g, const rt_render_params* 
   }
   const size_t bytes = (size_t)p->width * p->height * 3u * sizeof(double);
   HIP_TRY(hipSetDevice(g->members[0]->device));
+  int rc = group_wait(g, nullptr);  // frames queued through rt_group_render_device are not this call's
+  if (rc != RT_OK) return rc;
   if (g->stage_bytes < bytes) {
     if (g->stage) (void)hipFree(g->stage);
     g->stage = nullptr;
@@ -351,10 +423,15 @@ static int rt_group_render_accumulate_body(rt_group* g, const rt_render_params* 
   }
   // as rt_render_accumulate does: the frame alone crosses PCIe, once, into pinned memory, and is
   // added to the caller's canvas on the host (0 + x = x: the same bits as adding on the device)
-  HIP_TRY(hipMemset(g->stage, 0, bytes));  // group_render waits for the device before it queues anything
-  const int rc = group_render(g, p, split, g->stage, rays_out, "rt_group_render_accumulate");
-  if (rc != RT_OK) return rc;
-  HIP_TRY(hipMemcpy(g->host_stage, g->stage, bytes, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemsetAsync(g->stage, 0, bytes, g->own));  // the frame is ordered behind it through the stream
+  rc = group_queue_frame(g, p, split, g->stage, g->own, "rt_group_render_accumulate");
+  if (rc != RT_OK) {
+    (void)group_wait(g, nullptr);  // let what was queued run out; the caller's canvas is untouched
+    return rc;
+  }
+  HIP_TRY(hipMemcpyAsync(g->host_stage, g->stage, bytes, hipMemcpyDeviceToHost, g->own));
+  HIP_TRY(hipStreamSynchronize(g->own));
+  if ((rc = group_wait(g, rays_out)) != RT_OK) return rc;
   rt_add_into(canvas, static_cast<const double*>(g->host_stage), bytes / sizeof(double));
   return RT_OK;
 }

@@ -163,11 +163,14 @@ int main(int argc, char** argv) {
   for (uint32_t it = 0; it < its; ++it) {
     rt_render_params q = p;
     q.first_sample = p.first_sample + it * p.spp;  // fresh samples of each pixel's stream per call
-    if (group) {
-      uint64_t r = 0;
-      if (rt_group_render_device(group, &q, split, canvas, &r) != RT_OK) return die("rt_group_render_device");
-      rays += r;
-      if (progress && write_frame(out_path.c_str(), canvas, host, rgba, p.width, p.height, it + 1, stream)) return 1;
+    if (group) {  // frame follows frame: the members render the next one while this one is combined
+      if (rt_group_render_device(group, &q, split, canvas, stream) != RT_OK) return die("rt_group_render_device");
+      if (progress) {  // showing a frame ends the run
+        uint64_t r = 0;
+        if (rt_group_wait(group, &r) != RT_OK) return die("rt_group_wait");
+        rays += r;
+        if (write_frame(out_path.c_str(), canvas, host, rgba, p.width, p.height, it + 1, stream)) return 1;
+      }
       continue;
     }
     // frame follows frame: let each call's last kernels overlap the next call (a pipelined run)
@@ -179,6 +182,9 @@ int main(int argc, char** argv) {
       rays += st.rays;
       if (write_frame(out_path.c_str(), canvas, host, rgba, p.width, p.height, it + 1, stream)) return 1;
     }
+  }
+  if (!progress && group) {
+    if (rt_group_wait(group, &rays) != RT_OK) return die("rt_group_wait");
   }
   if (!progress && !group) {  // waits for the run and reports its totals
     rt_stats st;
@@ -199,7 +205,7 @@ int main(int argc, char** argv) {
       uint64_t r = 0;
       double ms = 0.0;
       rt_group_member_info(group, i, &dev, &r, &ms);
-      std::fprintf(stderr, "rt_render:   member %u on device %d: last frame %llu rays in %.2f ms\n", i, dev, (unsigned long long)r, ms);
+      std::fprintf(stderr, "rt_render:   member %u on device %d: %llu rays since the last wait, its share of the last frame took %.2f ms\n", i, dev, (unsigned long long)r, ms);
     }
     rt_group_destroy(group);
   }

@@ -372,13 +372,21 @@ class Group:
         check(lib.rt_group_render_accumulate(self._h, C.byref(params), int(split), _ptr(canvas), C.byref(rays)), "rt_group_render_accumulate")
         return rays.value
 
-    def render_device(self, device_canvas_ptr, params, split=_ffi.RT_SPLIT_SAMPLES):
+    def render_device(self, device_canvas_ptr, params, split=_ffi.RT_SPLIT_SAMPLES, stream=None):
+        """Queues one frame into a canvas in the first device's memory and returns; `stream` orders
+        the canvas (the frame is added behind what the stream held, later work on it sees the frame)."""
+        check(lib.rt_group_render_device(self._h, C.byref(params), int(split), C.c_void_p(device_canvas_ptr), C.c_void_p(stream or 0)), "rt_group_render_device")
+
+    def wait(self):
+        """Waits for every frame queued so far; returns the nearest-hit queries of all members in the
+        frames since the previous wait."""
         rays = C.c_uint64()
-        check(lib.rt_group_render_device(self._h, C.byref(params), int(split), C.c_void_p(device_canvas_ptr), C.byref(rays)), "rt_group_render_device")
+        check(lib.rt_group_wait(self._h, C.byref(rays)), "rt_group_wait")
         return rays.value
 
     def member_info(self, member):
-        """(device, nearest-hit queries, milliseconds) of one member's share of the last frame."""
+        """(device, nearest-hit queries, milliseconds) of one member: queries in the frames the latest
+        wait covered, time of its share of the latest of them."""
         dev, rays, ms = C.c_int(), C.c_uint64(), C.c_double()
         check(lib.rt_group_member_info(self._h, int(member), C.byref(dev), C.byref(rays), C.byref(ms)), "rt_group_member_info")
         return dev.value, rays.value, ms.value

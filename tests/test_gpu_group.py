@@ -90,7 +90,8 @@ def test_more_members_than_samples_and_a_device_canvas(spot):
     c = np.zeros((H, W, 3))
     want_rays = spot.render(c, p)
     dc = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")
-    rays = g.render_device(dc.data_ptr(), p, _ffi.RT_SPLIT_SAMPLES)
+    g.render_device(dc.data_ptr(), p, _ffi.RT_SPLIT_SAMPLES, torch.cuda.current_stream().cuda_stream)
+    rays = g.wait()
     assert rays == want_rays
     assert sorted(g.member_info(i)[1] > 0 for i in range(4)) == [False, False, True, True]
     np.testing.assert_allclose(dc.cpu().numpy(), c, rtol=1e-6, atol=1e-9)
@@ -131,3 +132,45 @@ def test_a_member_the_first_device_cannot_reach_is_refused(monkeypatch):
     assert e.value.code == _ffi.RT_ERR_HIP and "cannot access" in str(e.value)
     monkeypatch.delenv("RT_GROUP_NO_PEER")
     assert len(rt.Group(s, [0, 0])) == 2
+
+
+@pytest.mark.parametrize("split,n", [(_ffi.RT_SPLIT_SAMPLES, 3), (_ffi.RT_SPLIT_TILES, 4)])
+def test_frames_queued_back_to_back_equal_frames_one_by_one(spot, split, n):
+    """rt_group_render_device only queues: the members render frame k + 1 (into their other sum
+    buffer) while the first device combines frame k, ordered by events alone. A run of frames
+    queued without a wait in between must leave the bits that the same frames leave when each is
+    waited for — and the canvas is ordered by the caller's stream: a clear queued on it before
+    the first frame, and a copy queued on it after the last, need no synchronisation."""
+    frames = 6
+    ps = [params(first_sample=k * SPP, fov_y_deg=40.0 + 15.0 * k) for k in range(frames)]  # frames that differ in work
+    one_by_one = rt.Group(spot, [0] * n)
+    want = np.zeros((H, W, 3))
+    rays_want = 0
+    for p in ps:
+        rays_want += one_by_one.render(want, p, split)
+    g = rt.Group(spot, [0] * n)
+    side = torch.cuda.Stream()
+    dc = torch.full((H, W, 3), 7.0, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        dc.zero_()  # on the caller's stream: the first frame's combination must come after it
+        for p in ps:
+            g.render_device(dc.data_ptr(), p, split, side.cuda_stream)
+        got = dc.clone()  # on the caller's stream, behind the last combination
+    side.synchronize()
+    rays = g.wait()
+    assert rays == rays_want
+    assert sum(g.member_info(i)[1] for i in range(n)) == rays
+    # the host-canvas entry point adds frame by frame in binary64 on the host, the device one on the
+    # device: the same additions in the same order
+    assert got.cpu().numpy().tobytes() == want.tobytes()
+    assert g.wait() == 0  # nothing queued since
+    # a frame of another size afterwards (the sum buffers grow), then the first size again
+    small = torch.zeros((40, 56, 3), dtype=torch.float64, device="cuda")
+    ref = np.zeros((40, 56, 3))
+    one_by_one.render(ref, params(width=56, height=40), split)
+    with torch.cuda.stream(side):
+        g.render_device(small.data_ptr(), params(width=56, height=40), split, side.cuda_stream)
+        g.render_device(dc.data_ptr(), ps[0], split, side.cuda_stream)
+    g.wait()
+    assert small.cpu().numpy().tobytes() == ref.tobytes()

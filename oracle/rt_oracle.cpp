@@ -178,6 +178,7 @@ inline uint64_t rng_path_key(uint64_t seed, uint64_t pixel, uint64_t sample) {
   k = mix64(k + GOLDEN * (sample + 1));
   return k;
 }
+const uint32_t JITTER_STREAM = 1u << 19;  // first draw index of a shading stage's second stream (a stage has 2^20 indices)
 struct Rng {
   uint64_t key;
   uint64_t stage_base;
@@ -703,11 +704,17 @@ void raytrace(TraceCtx& cx, const Vec3& origin, const Vec3& dir, int depth, doub
     double reflected[3] = {0.0, 0.0, 0.0};
     // NUM_SAMPLES_PER_BOUNCE = 1 (:1045): the loop body runs once
     {
-      Vec3 m = mat.metallic * random_unit_sphere_surface(rng);  // :869
+      // The metal jitter and the three unused draws take their uniforms from a stream of their own
+      // (indices from JITTER_STREAM on), the hemisphere sample below from index 0 on: where a draw's
+      // uniform comes from is this restatement's choice (the reference asks thread_rng), and with
+      // two streams the hemisphere sample does not depend on how many pairs the jitter rejected.
+      Rng jit = rng;
+      jit.index = JITTER_STREAM;
+      Vec3 m = mat.metallic * random_unit_sphere_surface(jit);  // :869
       // :871-873 three draws whose values are never used
-      (void)rng.range(-mat.diffuse, mat.diffuse);
-      (void)rng.range(-mat.diffuse, mat.diffuse);
-      (void)rng.range(-mat.diffuse, mat.diffuse);
+      (void)jit.range(-mat.diffuse, mat.diffuse);
+      (void)jit.range(-mat.diffuse, mat.diffuse);
+      (void)jit.range(-mat.diffuse, mat.diffuse);
 
       Vec3 diffuse_out = V(0.0, 0.0, 0.0);
       bool found = false;

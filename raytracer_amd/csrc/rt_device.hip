@@ -1164,7 +1164,9 @@ __global__ __launch_bounds__(RT_PLAN_THREADS) void k_plan(unsigned long long* co
 // the end — the form that cannot fall short whatever the counts turn out to be; it holds more
 // registers, so the host launches the first form on a grid sized from experience and the second
 // behind it for whatever that grid did not cover (normally nothing).
-template <bool COUNT, int STAGE, bool LOOP, bool QUANT>
+// EMIT = false: for scenes without emitters (sc.has_emission == 0); the radiance a path has
+// gathered so far is then zero until its last ray, and is neither carried in registers nor queued.
+template <bool COUNT, int STAGE, bool LOOP, bool QUANT, bool EMIT>
 __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, QueueView in, QueueView out, uint32_t n_seg,
                                                    const PlanRec* __restrict__ plan, uint32_t vb_base, double* __restrict__ samples,
                                                    unsigned long long* counters) {
@@ -1229,7 +1231,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
       key = r->key;
       path = r->path;
       depth = r->depth;
-      if (sc.has_emission) rad = mk(in.rad[entry * 3], in.rad[entry * 3 + 1], in.rad[entry * 3 + 2]);
+      if (EMIT) rad = mk(in.rad[entry * 3], in.rad[entry * 3 + 1], in.rad[entry * 3 + 2]);
       ShadeIn si;
       si.hit_pos = p0;
       si.u = r->u;
@@ -1238,12 +1240,25 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
       si.slot = id >= 0 ? id : -1;
       si.sphere = id >= 0 ? -1 : ~id;
       if (COUNT) wc.shaded++;
-      shade_hit<COUNT>(sc, si, key, depth, o, dir, thr, rad, wc);
+      shade_hit<COUNT, EMIT>(sc, si, key, depth, o, dir, thr, rad, wc);
       depth += 1;
       if (depth > pp.max_depth) {  // src/main.rs:818
         store_sample(samples, pp.n_paths, path, rad);
         alive = false;
         n_done++;
+      }
+      // What the walk through the tree does not need waits in the record the lane has just read (the
+      // throughput, which shading has changed, is written over the old one; key, path and depth are
+      // still there) and is read back behind the walk: ten registers fewer where the kernel holds most.
+      if (STAGE == 1 && alive) {
+        in.recs[(size_t)3 * in.entries + entry] = make_float4(__int_as_float(__double2loint(thr.x)), __int_as_float(__double2hiint(thr.x)),
+                                                              __int_as_float(__double2loint(thr.y)), __int_as_float(__double2hiint(thr.y)));
+        reinterpret_cast<double*>(in.recs + (size_t)4 * in.entries + entry)[0] = thr.z;
+        if (EMIT) {
+          in.rad[entry * 3] = rad.x;
+          in.rad[entry * 3 + 1] = rad.y;
+          in.rad[entry * 3 + 2] = rad.z;
+        }
       }
     }
   }
@@ -1261,6 +1276,17 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
       trav_begin<QUANT>(t, sc, o, dir, stk);
       trav_run<COUNT, QUANT>(t, sc, stride, wc);
       steps = t.steps;
+      if (STAGE == 1) {
+        asm volatile("" ::: "memory");  // the values parked before the walk are read again, not kept
+        const double2 p3 = reinterpret_cast<const double2*>(in.recs)[(size_t)3 * in.entries + entry];
+        const double2 p4 = reinterpret_cast<const double2*>(in.recs)[(size_t)4 * in.entries + entry];
+        const float4 p5 = in.recs[(size_t)5 * in.entries + entry], p6 = in.recs[(size_t)6 * in.entries + entry];
+        thr = mk(p3.x, p3.y, p4.x);
+        key = ((uint64_t)(uint32_t)__float_as_int(p5.w) << 32) | (uint32_t)__float_as_int(p5.z);
+        path = (uint32_t)__float_as_int(p6.x);
+        depth = __float_as_int(p6.z) + 1;
+        if (EMIT) rad = mk(in.rad[entry * 3], in.rad[entry * 3 + 1], in.rad[entry * 3 + 2]);
+      }
       wc.rays++;
       finish_hit<COUNT>(sc, t, h, wc);
       if (!(h.slot >= 0 || h.sphere >= 0)) {
@@ -1277,7 +1303,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
     if (alive) {
       if (COUNT) wc.shaded++;
       const ShadeIn si = shade_input(h, o, dir);
-      shade_hit<COUNT>(sc, si, key, depth, o, dir, thr, rad, wc);
+      shade_hit<COUNT, EMIT>(sc, si, key, depth, o, dir, thr, rad, wc);
       depth += 1;
       if (depth > pp.max_depth) {
         store_sample(samples, pp.n_paths, path, rad);
@@ -1342,7 +1368,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
       r->depth = depth;
       r->pad = steps;
       queue_store(out, e, rec_out);
-      if (sc.has_emission) {
+      if (EMIT) {
         out.rad[e * 3] = rad.x;
         out.rad[e * 3 + 1] = rad.y;
         out.rad[e * 3 + 2] = rad.z;
@@ -1546,28 +1572,33 @@ static uint64_t queue_entries(uint32_t n_paths) {
 template <bool COUNT, int STAGE, bool LOOP, bool QUANT>
 static void launch_wave_as(dim3 grid, size_t lds, hipStream_t st, const SceneK& k, const PathParams& pp, const QueueView& in, const QueueView& out,
                            uint32_t n_seg, const PlanRec* plan, uint32_t vb_base, double* samples, unsigned long long* counters) {
-  hipLaunchKernelGGL((k_wave<COUNT, STAGE, LOOP, QUANT>), grid, dim3(RT_BLOCK), lds, st, k, pp, in, out, n_seg, plan, vb_base, samples, counters);
+  if (k.has_emission)
+    hipLaunchKernelGGL((k_wave<COUNT, STAGE, LOOP, QUANT, true>), grid, dim3(RT_BLOCK), lds, st, k, pp, in, out, n_seg, plan, vb_base, samples, counters);
+  else
+    hipLaunchKernelGGL((k_wave<COUNT, STAGE, LOOP, QUANT, false>), grid, dim3(RT_BLOCK), lds, st, k, pp, in, out, n_seg, plan, vb_base, samples, counters);
 }
 template <int STAGE>
 static void launch_wave(bool count, bool loop, bool quant, dim3 grid, size_t lds, hipStream_t st, const SceneK& k, const PathParams& pp, const QueueView& in,
                         const QueueView& out, uint32_t n_seg, const PlanRec* plan, uint32_t vb_base, double* samples, unsigned long long* counters) {
 #define RT_LAUNCH_AS(C, L, Q) launch_wave_as<C, STAGE, L, Q>(grid, lds, st, k, pp, in, out, n_seg, plan, vb_base, samples, counters)
-  if (STAGE == 1 && quant) {
-    if (!loop) {
-      if (count) RT_LAUNCH_AS(true, false, (STAGE == 1));
-      else RT_LAUNCH_AS(false, false, (STAGE == 1));
-    } else {
-      if (count) RT_LAUNCH_AS(true, true, (STAGE == 1));
-      else RT_LAUNCH_AS(false, true, (STAGE == 1));
+  if constexpr (STAGE == 1) {
+    if (quant) {
+      if (!loop) {
+        if (count) RT_LAUNCH_AS(true, false, true);
+        else RT_LAUNCH_AS(false, false, true);
+      } else {
+        if (count) RT_LAUNCH_AS(true, true, true);
+        else RT_LAUNCH_AS(false, true, true);
+      }
+      return;
     }
+  }
+  if (!loop) {
+    if (count) RT_LAUNCH_AS(true, false, false);
+    else RT_LAUNCH_AS(false, false, false);
   } else {
-    if (!loop) {
-      if (count) RT_LAUNCH_AS(true, false, false);
-      else RT_LAUNCH_AS(false, false, false);
-    } else {
-      if (count) RT_LAUNCH_AS(true, true, false);
-      else RT_LAUNCH_AS(false, true, false);
-    }
+    if (count) RT_LAUNCH_AS(true, true, false);
+    else RT_LAUNCH_AS(false, true, false);
   }
 #undef RT_LAUNCH_AS
 }

@@ -86,6 +86,7 @@ __device__ __forceinline__ d3 normalize(d3 a) { return div3_by_length(a, length(
 // counter-based generator: draw = mix64(key + GOLDEN * ((stage << 20) + index + 1)), 52 bits
 // ------------------------------------------------------------------------------------------
 #define RT_GOLDEN 0x9e3779b97f4a7c15ull
+#define RT_JITTER_STREAM (1u << 19) /* first draw index of a shading stage's second stream (a stage has 2^20 indices) */
 
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {
   z ^= z >> 30;
@@ -599,7 +600,9 @@ struct ShadeIn {
   int32_t sphere;  // sphere record index, or -1
 };
 
-template <bool COUNT>
+// EMIT = false: the scene has no emitter, so the emitted radiance a path carries stays what it was
+// (zero) and costs no registers.
+template <bool COUNT, bool EMIT = true>
 __device__ __forceinline__ void shade_hit(const SceneK& sc, const ShadeIn& h, const uint64_t key, const int depth, d3& o,
                                           d3& dir, d3& thr, d3& rad, WorkCount& wc) {
   const double eps = 0.00000001;
@@ -660,25 +663,16 @@ __device__ __forceinline__ void shade_hit(const SceneK& sc, const ShadeIn& h, co
     const double metallic = m->metallic, diffuse = m->diffuse, how_metallic = m->how_metallic;
     // src/main.rs:925-929 unrolled: L = albedo * (L_in + emission)
     thr = mk(thr.x * point.x, thr.y * point.y, thr.z * point.z);
-    rad = rad + mk(thr.x * m->emission[0], thr.y * m->emission[1], thr.z * m->emission[2]);
+    if (EMIT) rad = rad + mk(thr.x * m->emission[0], thr.y * m->emission[1], thr.z * m->emission[2]);
     // src/main.rs:869-883. The reference draws a Marsaglia point for the metal jitter (rejection
     // loop 265-278), three unused uniforms (871-873), then Marsaglia points until one lies in the
-    // normal's hemisphere (876-883). Here the same draws are consumed in the same order by two
-    // loops that only DECIDE — how many candidate pairs the jitter takes, which pair the hemisphere
-    // sample takes — and the points are built afterwards, once, from the chosen pairs.
+    // normal's hemisphere (876-883). Here the hemisphere loop only DECIDES which candidate pair it
+    // takes, and the point is built afterwards, once, from the chosen pair.
     RT_ACC(wc, 0);
-    // (a) the jitter's pairs: up to and including the first whose squared length is below one
-    // (not unrolled: four in five lanes are done after the first pair, and a wave issues every
-    // instruction of an unrolled body for the one lane that is not)
-#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-    for (int tries = 0; tries < RT_REJECT_CAP; ++tries) {
-      if (COUNT && first_active_lane()) wc.wi_reject++;
-      double x1, x2;
-      rng.pair_pm1(x1, x2);
-      if (!(x1 * x1 + x2 * x2 >= 1.0)) break;
-    }
-    rng.skip(3);
-    // (b) the hemisphere sample. One loop over candidate pairs (nested loops would cost a wave the
+    // The hemisphere sample takes its uniforms from the stage's draws 0, 1, ...; the jitter and the
+    // three unused draws take theirs from a stream of their own (RT_JITTER_STREAM), so that a
+    // material whose jitter never reaches the result (below) does not draw it at all.
+    // The hemisphere sample: one loop over candidate pairs (nested loops would cost a wave the
     // maximum trip count of every level): `inner` counts the pairs of the current Marsaglia call,
     // `outer` the calls. Whether a point lies in the hemisphere is the sign of dot(point, normal) as
     // the reference rounds it; the loop first forms that dot product with the hardware's
@@ -751,14 +745,18 @@ __device__ __forceinline__ void shade_hit(const SceneK& sc, const ShadeIn& h, co
         r = 2.0 * cdn * normal - camera_dir;
       }
       const d3 reflected_camera = normalize(r);
-      // the jitter's point: the stage's draws once more from their start, as loop (a) took them
-      Rng again;
-      again.start(key, (uint32_t)depth + 1u);
+      // the jitter's point, from the stage's second stream (not unrolled: four in five lanes are done
+      // after the first pair, and a wave issues every instruction of an unrolled body for the one
+      // lane that is not)
+      Rng jrng;
+      jrng.start(key, (uint32_t)depth + 1u);
+      jrng.skip(RT_JITTER_STREAM);
       d3 pt = mk(0.0, 0.0, 1.0);  // fallback after RT_REJECT_CAP rejections
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
       for (int tries = 0; tries < RT_REJECT_CAP; ++tries) {
+        if (COUNT && first_active_lane()) wc.wi_reject++;
         double j1, j2;
-        again.pair_pm1(j1, j2);
+        jrng.pair_pm1(j1, j2);
         if (!(j1 * j1 + j2 * j2 >= 1.0)) {
           pt = marsaglia_point(j1, j2);
           break;

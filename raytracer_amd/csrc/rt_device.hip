@@ -51,6 +51,7 @@ using namespace rtk;
 #endif
 #define RT_LEAVE_DEFAULT 32      /* of 64: share of a wave's traversing lanes below which node steps pause for the leaves (trav_run) */
 #define RT_LONG_STEPS_DEFAULT 8u /* node visits from which a ray counts as long (see k_wave) */
+#define RT_DEEP_FROM 40          /* stack entries (tree depth + 2) from which the kernels' DEEP form runs (trav_run) */
 // words of a line
 enum { CNT_RAYS = 0, CNT_NODES, CNT_TRIS, CNT_SPHERES, CNT_SHADED, CNT_PATHS, CNT_Q0, CNT_R0, CNT_Q1, CNT_R1, CNT_WORK, CNT_WI_INNER, CNT_WI_LEAF, CNT_WI_REJECT, CNT_WAVES, CNT_N };
 #define RT_COUNTER_BYTES ((size_t)RT_SHARDS * RT_LINE_WORDS * sizeof(unsigned long long))
@@ -375,6 +376,11 @@ int rt_device_scene_upload_from(const rt_scene* s, rt_scene* target, int device)
   for (const rt_material& m : s->materials)
     if (m.emission[0] != 0.0 || m.emission[1] != 0.0 || m.emission[2] != 0.0) d->k.has_emission = 1;
   d->stack_entries = s->bvh_depth + 2;
+  {
+    // RT_DEEP_STACK=0/1 forces the choice (A/B)
+    const char* e = std::getenv("RT_DEEP_STACK");
+    d->k.deep_stack = e && *e ? (*e != '0' && d->stack_entries > (uint32_t)RT_DEEP_LDS ? 1u : 0u) : (d->stack_entries >= (uint32_t)RT_DEEP_FROM ? 1u : 0u);
+  }
   if (hipMalloc((void**)&d->counters, RT_COUNTER_BYTES) != hipSuccess) {
     rt_set_error("rt_scene_upload: hipMalloc of the counters failed");
     return fail(RT_ERR_HIP);
@@ -740,7 +746,7 @@ __device__ __forceinline__ void flush_counts(const WorkCount& wc, unsigned long 
   }
 }
 
-template <bool COUNT>
+template <bool COUNT, bool DEEP>
 __global__ __launch_bounds__(RT_BLOCK) void k_trace(SceneK sc, const double* __restrict__ org, const double* __restrict__ dir,
                                                     size_t n, rt_hit* __restrict__ out, unsigned long long* counters) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -749,13 +755,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(SceneK sc, const double* __r
     const d3 o = mk(org[i * 3], org[i * 3 + 1], org[i * 3 + 2]);
     const d3 d = mk(dir[i * 3], dir[i * 3 + 1], dir[i * 3 + 2]);
     HitK h;
-    trace_ray<COUNT>(sc, o, d, g_stack + threadIdx.x, blockDim.x, h, wc);
+    trace_ray<COUNT, DEEP>(sc, o, d, g_stack + threadIdx.x, blockDim.x, h, wc);
     wc.rays = 1;
     store_hit(sc, h, out + i);
   }
   flush_counts(wc, counters, COUNT, 0);
 }
 
+template <bool DEEP>
 __global__ __launch_bounds__(RT_BLOCK) void k_primary(SceneK sc, CameraK cam, int32_t* __restrict__ obj, int32_t* __restrict__ tri,
                                                       double* __restrict__ t, double* __restrict__ u, double* __restrict__ v,
                                                       unsigned long long* counters) {
@@ -767,7 +774,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_primary(SceneK sc, CameraK cam, in
     d3 o, d;
     camera_ray(cam, px, py, 0ull, o, d);
     HitK h;
-    trace_ray<false>(sc, o, d, g_stack + threadIdx.x, blockDim.x, h, wc);
+    trace_ray<false, DEEP>(sc, o, d, g_stack + threadIdx.x, blockDim.x, h, wc);
     wc.rays = 1;
     rt_hit r;
     store_hit(sc, h, &r);
@@ -885,7 +892,7 @@ __device__ __forceinline__ ShadeIn shade_input(const HitK& h, const d3 o, const 
 // counter (in wave-local batches of RT_WORK_BATCH, so the counter sees one atomic per 1024
 // paths); otherwise one thread per path.
 // ------------------------------------------------------------------------------------------
-template <bool COUNT, bool REGEN>
+template <bool COUNT, bool REGEN, bool DEEP>
 __global__ __launch_bounds__(RT_BLOCK) void k_paths(SceneK sc, PathParams pp, double* __restrict__ samples,
                                                     unsigned long long* counters) {
   int32_t* stk = g_stack + threadIdx.x;
@@ -951,7 +958,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_paths(SceneK sc, PathParams pp, do
     if (alive) {
       HitK h;
       wc.rays++;
-      trace_ray<COUNT>(sc, o, dir, stk, stride, h, wc);
+      trace_ray<COUNT, DEEP>(sc, o, dir, stk, stride, h, wc);
       bool finished;
       if (h.slot < 0 && h.sphere < 0) {
         const d3 s = sky(sc, dir);  // src/main.rs:826
@@ -1166,7 +1173,7 @@ __global__ __launch_bounds__(RT_PLAN_THREADS) void k_plan(unsigned long long* co
 // behind it for whatever that grid did not cover (normally nothing).
 // EMIT = false: for scenes without emitters (sc.has_emission == 0); the radiance a path has
 // gathered so far is then zero until its last ray, and is neither carried in registers nor queued.
-template <bool COUNT, int STAGE, bool LOOP, bool QUANT, bool EMIT>
+template <bool COUNT, int STAGE, bool LOOP, bool QUANT, bool EMIT, bool DEEP>
 __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, QueueView in, QueueView out, uint32_t n_seg,
                                                    const PlanRec* __restrict__ plan, uint32_t vb_base, double* __restrict__ samples,
                                                    unsigned long long* counters) {
@@ -1274,7 +1281,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
       // bound by node-fetch instructions. The tail is a few waves' serial chain, bound by latency:
       // there the binary32 nodes (no conversions between the fetch and the tests) are quicker.
       trav_begin<QUANT>(t, sc, o, dir, stk);
-      trav_run<COUNT, QUANT>(t, sc, stride, wc);
+      trav_run<COUNT, QUANT, DEEP>(t, sc, stride, wc);
       steps = t.steps;
       if (STAGE == 1) {
         asm volatile("" ::: "memory");  // the values parked before the walk are read again, not kept
@@ -1464,7 +1471,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(TileMap tm, const double* 
 // ------------------------------------------------------------------------------------------
 // entry points
 // ------------------------------------------------------------------------------------------
-static size_t stack_lds_bytes(const DeviceScene* d) { return (size_t)d->stack_entries * RT_BLOCK * sizeof(int32_t); }
+// LDS of a workgroup: the traversal stack, one column per lane. A tree deeper than RT_DEEP_FROM
+// entries runs the kernels' DEEP form, which keeps RT_DEEP_LDS entries there.
+static size_t stack_lds_bytes(const DeviceScene* d) {
+  const uint32_t entries = d->k.deep_stack ? (uint32_t)RT_DEEP_LDS : d->stack_entries;
+  return (size_t)entries * RT_BLOCK * sizeof(int32_t);
+}
 
 static int check_params(const rt_render_params* p, const char* who) {
   if (!p) {
@@ -1572,10 +1584,17 @@ static uint64_t queue_entries(uint32_t n_paths) {
 template <bool COUNT, int STAGE, bool LOOP, bool QUANT>
 static void launch_wave_as(dim3 grid, size_t lds, hipStream_t st, const SceneK& k, const PathParams& pp, const QueueView& in, const QueueView& out,
                            uint32_t n_seg, const PlanRec* plan, uint32_t vb_base, double* samples, unsigned long long* counters) {
-  if (k.has_emission)
-    hipLaunchKernelGGL((k_wave<COUNT, STAGE, LOOP, QUANT, true>), grid, dim3(RT_BLOCK), lds, st, k, pp, in, out, n_seg, plan, vb_base, samples, counters);
-  else
-    hipLaunchKernelGGL((k_wave<COUNT, STAGE, LOOP, QUANT, false>), grid, dim3(RT_BLOCK), lds, st, k, pp, in, out, n_seg, plan, vb_base, samples, counters);
+  const bool deep = k.deep_stack != 0u;
+#define RT_LAUNCH_K(E, D) \
+  hipLaunchKernelGGL((k_wave<COUNT, STAGE, LOOP, QUANT, E, D>), grid, dim3(RT_BLOCK), lds, st, k, pp, in, out, n_seg, plan, vb_base, samples, counters)
+  if (k.has_emission) {
+    if (deep) RT_LAUNCH_K(true, true);
+    else RT_LAUNCH_K(true, false);
+  } else {
+    if (deep) RT_LAUNCH_K(false, true);
+    else RT_LAUNCH_K(false, false);
+  }
+#undef RT_LAUNCH_K
 }
 template <int STAGE>
 static void launch_wave(bool count, bool loop, bool quant, dim3 grid, size_t lds, hipStream_t st, const SceneK& k, const PathParams& pp, const QueueView& in,
@@ -1847,11 +1866,13 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
       }
       if ((rc = begin_launch(3, pp.n_paths, stream)) != RT_OK) return rc;
       if (regen) {
-        if (count) hipLaunchKernelGGL((k_paths<true, true>), dim3(grid), dim3(RT_BLOCK), lds, stream, d->k, pp, samples, counters);
-        else hipLaunchKernelGGL((k_paths<false, true>), dim3(grid), dim3(RT_BLOCK), lds, stream, d->k, pp, samples, counters);
+        if (d->k.deep_stack) hipLaunchKernelGGL((k_paths<true, true, true>), dim3(grid), dim3(RT_BLOCK), lds, stream, d->k, pp, samples, counters);
+        else if (count) hipLaunchKernelGGL((k_paths<true, true, false>), dim3(grid), dim3(RT_BLOCK), lds, stream, d->k, pp, samples, counters);
+        else hipLaunchKernelGGL((k_paths<false, true, false>), dim3(grid), dim3(RT_BLOCK), lds, stream, d->k, pp, samples, counters);
       } else {
-        if (count) hipLaunchKernelGGL((k_paths<true, false>), dim3(grid), dim3(RT_BLOCK), lds, stream, d->k, pp, samples, counters);
-        else hipLaunchKernelGGL((k_paths<false, false>), dim3(grid), dim3(RT_BLOCK), lds, stream, d->k, pp, samples, counters);
+        if (d->k.deep_stack) hipLaunchKernelGGL((k_paths<true, false, true>), dim3(grid), dim3(RT_BLOCK), lds, stream, d->k, pp, samples, counters);
+        else if (count) hipLaunchKernelGGL((k_paths<true, false, false>), dim3(grid), dim3(RT_BLOCK), lds, stream, d->k, pp, samples, counters);
+        else hipLaunchKernelGGL((k_paths<false, false, false>), dim3(grid), dim3(RT_BLOCK), lds, stream, d->k, pp, samples, counters);
       }
       if ((rc = end_launch(stream)) != RT_OK) return rc;
       if ((rc = take_plan(stream, counters, CNT_Q0, CNT_R0, -1, 0u, 0u, 0u, &snap)) != RT_OK) return rc;
@@ -2126,7 +2147,8 @@ static int rt_trace_body(rt_scene* s, const double* org3, const double* dir3, si
   d->cur_counters = d->counters;
   HIP_TRY(hipMemsetAsync(d->counters, 0, RT_COUNTER_BYTES, d->own));
   const uint32_t grid = (uint32_t)((n + RT_BLOCK - 1) / RT_BLOCK);
-  hipLaunchKernelGGL((k_trace<true>), dim3(grid), dim3(RT_BLOCK), stack_lds_bytes(d), d->own, d->k, d_org, d_dir, n, d_hit, d->counters);
+  if (d->k.deep_stack) hipLaunchKernelGGL((k_trace<true, true>), dim3(grid), dim3(RT_BLOCK), stack_lds_bytes(d), d->own, d->k, d_org, d_dir, n, d_hit, d->counters);
+  else hipLaunchKernelGGL((k_trace<true, false>), dim3(grid), dim3(RT_BLOCK), stack_lds_bytes(d), d->own, d->k, d_org, d_dir, n, d_hit, d->counters);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(out, d_hit, hit_bytes, hipMemcpyDeviceToHost, d->own));
   HIP_TRY(hipStreamSynchronize(d->own));
@@ -2165,7 +2187,8 @@ static int rt_primary_hits_body(rt_scene* s, const rt_render_params* p, int32_t*
   d->cur_counters = d->counters;
   HIP_TRY(hipMemsetAsync(d->counters, 0, RT_COUNTER_BYTES, d->own));
   const uint32_t grid = (uint32_t)((npix + RT_BLOCK - 1) / RT_BLOCK);
-  hipLaunchKernelGGL(k_primary, dim3(grid), dim3(RT_BLOCK), stack_lds_bytes(d), d->own, d->k, cam, d_obj, d_tri, d_t, d_u, d_v, d->counters);
+  if (d->k.deep_stack) hipLaunchKernelGGL(k_primary<true>, dim3(grid), dim3(RT_BLOCK), stack_lds_bytes(d), d->own, d->k, cam, d_obj, d_tri, d_t, d_u, d_v, d->counters);
+  else hipLaunchKernelGGL(k_primary<false>, dim3(grid), dim3(RT_BLOCK), stack_lds_bytes(d), d->own, d->k, cam, d_obj, d_tri, d_t, d_u, d_v, d->counters);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(t, d_t, npix * sizeof(double), hipMemcpyDeviceToHost, d->own));
   HIP_TRY(hipMemcpyAsync(u, d_u, npix * sizeof(double), hipMemcpyDeviceToHost, d->own));

@@ -174,6 +174,7 @@ struct SceneK {
   double sky_light[3];    // normalize((1, 2, 1)), src/main.rs:307
   unsigned long long sph_always;  // bit i: sphere i (< 64) has no place in the tree and is tested against every ray
   uint32_t sph_places;            // some sphere has a place in the tree
+  uint32_t deep_stack;            // host side: the tree is deep enough for the kernels' DEEP form (trav_run)
 };
 
 struct HitK {
@@ -252,6 +253,7 @@ struct Trav {
   int32_t best_slot, best_flat;
   int32_t cur;   // next node/leaf ref, RT_REF_SENTINEL when the traversal has finished
   int32_t* sp;   // top of the stack column (entries are `stride` ints apart)
+  int32_t* base; // bottom of the stack column
   int32_t steps; // interior nodes this ray has visited
   unsigned long long spheres;  // bit i: the ray reached the place of sphere i in the tree
 };
@@ -308,6 +310,7 @@ __device__ __forceinline__ void trav_begin(Trav& t, const SceneK& sc, const d3 o
   t.best_slot = -1;
   t.best_flat = 0x7fffffff;
   t.sp = stk;
+  t.base = stk;
   *t.sp = RT_REF_SENTINEL;
   t.cur = sc.root_ref;
   t.steps = 0;
@@ -315,7 +318,14 @@ __device__ __forceinline__ void trav_begin(Trav& t, const SceneK& sc, const d3 o
 }
 
 // Runs the traversal to its end (t.cur == RT_REF_SENTINEL).
-template <bool COUNT, bool QUANT = false>
+// The stack is a full stack in LDS, sized from the tree's depth: up to 39 entries (10 KB a wave)
+// that costs a kernel of five waves per SIMD nothing. DEEP, for the trees beyond (the builders stop
+// at RT_BVH_MAX_DEPTH; only bottom-up clustering of a soup of overlapping triangles gets there):
+// RT_DEEP_LDS entries in LDS and the deeper ones in private memory, which keeps the waves a deep
+// stack would cost (measured on a soup's tree of depth 56: 2259 -> 1847 ms a frame) at the price
+// of a comparison on every push and pop (4-6 % on the scenes of ordinary depth, hence not for them).
+#define RT_DEEP_LDS 16
+template <bool COUNT, bool QUANT = false, bool DEEP = false>
 __device__ __forceinline__ void trav_run(Trav& t, const SceneK& sc, const int stride, WorkCount& wc) {
   const double eps = 0.00000001;  // src/main.rs:185
   const d3 o = t.o, d = t.d;
@@ -326,6 +336,20 @@ __device__ __forceinline__ void trav_run(Trav& t, const SceneK& sc, const int st
   int32_t best_slot = t.best_slot, best_flat = t.best_flat;
   int32_t cur = t.cur;
   int32_t* sp = t.sp;
+  // DEEP: the first RT_DEEP_LDS stack entries in LDS, deeper ones in the lane's private memory.
+  int32_t spill[DEEP ? RT_BVH_MAX_DEPTH + 2 - RT_DEEP_LDS : 1];
+  const int32_t* const lds_end = DEEP ? t.base + RT_DEEP_LDS * stride : nullptr;
+#define RT_PUSH(v)                                                   \
+  do {                                                               \
+    sp += stride;                                                    \
+    if (!DEEP || sp < lds_end) *sp = (v);                            \
+    else spill[(int)(sp - lds_end) / RT_BLOCK] = (v);                \
+  } while (0)
+#define RT_POP()                                                                       \
+  do {                                                                                 \
+    cur = (!DEEP || sp < lds_end) ? *sp : spill[(int)(sp - lds_end) / RT_BLOCK];       \
+    sp -= stride;                                                                      \
+  } while (0)
   int steps = 0;
   unsigned long long spheres = t.spheres;
 
@@ -391,16 +415,14 @@ __device__ __forceinline__ void trav_run(Trav& t, const SceneK& sc, const int st
         const bool swap = tn1 < tn0;
         const int32_t near = swap ? ch.y : ch.x;
         const int32_t far = swap ? ch.x : ch.y;
-        sp += stride;
-        *sp = far;
+        RT_PUSH(far);
         cur = near;
       } else if (h0) {
         cur = ch.x;
       } else if (h1) {
         cur = ch.y;
       } else {
-        cur = *sp;
-        sp -= stride;
+        RT_POP();
       }
     }
     RT_ACC(wc, 4);
@@ -442,10 +464,11 @@ __device__ __forceinline__ void trav_run(Trav& t, const SceneK& sc, const int st
         best32k = f32_up(dist) * RT_K_FAR;
       }
     }
-    cur = *sp;
-    sp -= stride;
+    RT_POP();
   }
   RT_ACC(wc, 5);
+#undef RT_PUSH
+#undef RT_POP
   t.best32k = best32k;
   t.best_t = best_t;
   t.best_u = best_u;
@@ -522,12 +545,12 @@ __device__ __forceinline__ void finish_hit(const SceneK& sc, const Trav& t, HitK
   RT_ACC(wc, 6);
 }
 
-template <bool COUNT>
+template <bool COUNT, bool DEEP = false>
 __device__ __forceinline__ void trace_ray(const SceneK& sc, const d3 o, const d3 d, int32_t* stk, const int stride,
                                           HitK& h, WorkCount& wc) {
   Trav t;
   trav_begin(t, sc, o, d, stk);
-  trav_run<COUNT>(t, sc, stride, wc);
+  trav_run<COUNT, false, DEEP>(t, sc, stride, wc);
   finish_hit<COUNT>(sc, t, h, wc);
 }
 

@@ -132,3 +132,45 @@ def test_scene_without_a_host_tree(oracle):
     s = rt.Scene.from_objects(objs, tree="none")
     assert s.hit([[0, 0, 0]], [[0, 0, -1]])["t"][0] == 2.0
 
+
+
+def _soup(n, seed=7):
+    """Large slivers through a common region: every box overlaps most others, so bottom-up clustering
+    chains the clusters into a tree several dozen levels deep."""
+    rng = np.random.default_rng(seed)
+    c = rng.normal(size=(n, 1, 3)) * 0.05 + np.array([0.0, 0.0, -3.0])
+    tv = c + rng.normal(size=(n, 3, 3)) * np.array([1.0, 1.0, 0.3]) * 10.0 ** rng.uniform(-2.0, 0.0, (n, 1, 1))
+    nrm = np.cross(tv[:, 1] - tv[:, 0], tv[:, 2] - tv[:, 0])
+    nrm /= np.maximum(1e-30, np.linalg.norm(nrm, axis=1, keepdims=True))
+    mat = rt.Opaque((0.6, 0.6, 0.6), 0, 0, 0.9)
+    return ([_ffi.RT_OBJ_MESH], [mat], tv, np.repeat(nrm[:, None, :], 3, axis=1), np.zeros((n, 3, 2)), [0] * n, list(range(n)), np.zeros((0, 4)), [])
+
+
+def test_deep_tree_short_stack(oracle, monkeypatch):
+    """A tree of 38 levels or more runs the kernels' form that keeps sixteen stack entries in LDS and
+    the deeper ones in private memory: same hits as the exhaustive test, and the same image and ray
+    count as the full LDS stack."""
+    args = _soup(4000)
+    images = {}
+    for deep in ("1", "0"):
+        monkeypatch.setenv("RT_DEEP_STACK", deep)
+        s = rt.Scene.from_desc(*args)
+        s.rebuild_on_device(0, "ploc")
+        assert s.info().bvh_depth >= 42, s.info().bvh_depth
+        if deep == "1":
+            o = oracle.OracleScene.from_desc_arrays(*args)
+            rng = np.random.default_rng(3)
+            org = rng.normal(size=(3000, 3)) * 2.0 + np.array([0.0, 0.0, -3.0])
+            d = rng.normal(size=(3000, 3))
+            co, cd = oracle.camera_rays(64, 48)
+            org, d = np.concatenate([org, co]), np.concatenate([d, cd])
+            assert s.hit(org, d).tobytes() == o.hit(org, d, oracle.HIT_BRUTE).tobytes()
+        canvas = np.zeros((54, 96, 3))
+        rays = s.render(canvas, rt.render_params(width=96, height=54, spp=4, seed=5))
+        images[deep] = (rays, canvas.tobytes())
+    monkeypatch.delenv("RT_DEEP_STACK")
+    s = rt.Scene.from_desc(*args)
+    s.rebuild_on_device(0, "ploc")  # by itself a tree this deep takes the short stack
+    canvas = np.zeros((54, 96, 3))
+    rays = s.render(canvas, rt.render_params(width=96, height=54, spp=4, seed=5))
+    assert images["1"] == images["0"] == (rays, canvas.tobytes())

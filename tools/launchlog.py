@@ -19,6 +19,7 @@ ap.add_argument("--spp", type=int, default=64)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--forms", default="wave,mega,noregen")
 ap.add_argument("--count", action="store_true")
+ap.add_argument("--show", type=int, default=14)
 ap.add_argument("--device-build", nargs="?", const="default", default=None, choices=["default", "lbvh", "ploc"],
                 help="replace the host-built tree by one built on the GPU")
 a = ap.parse_args()
@@ -32,7 +33,7 @@ if a.device_build:
 s.upload(0)
 print(f"tree: {s.info().bvh_nodes} nodes, {s.info().bvh_leaves} leaves, depth {s.info().bvh_depth}")
 canvas = torch.zeros((a.height, a.width, 3), dtype=torch.float64, device="cuda")
-KIND = {0: "first", 1: "bounce", 2: "tail", 3: "single", 4: "resolve", 5: "shade", 6: "extend"}
+KIND = {0: "first", 1: "bounce", 2: "tail", 3: "single", 4: "resolve", 5: "continue"}
 FORMS = {"wave": 0, "mega": _ffi.RT_FLAG_MEGAKERNEL, "noregen": _ffi.RT_FLAG_NO_REGEN}
 for form in a.forms.split(","):
     flags = FORMS[form] | _ffi.RT_FLAG_TIMING | (_ffi.RT_FLAG_COUNT_WORK if a.count else 0)
@@ -45,7 +46,7 @@ for form in a.forms.split(","):
     tm = s.last_timing()
     rays = sum(l.rays for l in log)
     print(f"== {form}: wall {wall:.2f} ms, kernels {tm.ms_paths:.2f} + resolve {tm.ms_resolve:.2f} ms, {rays} rays, {rays / wall / 1e3:.0f} Mrays/s, {len(log)} launches")
-    for l in log[:14]:
+    for l in log[:a.show]:
         extra = (f" nodes/ray {l.node_visits / max(1, l.rays):.2f} tris/ray {l.tri_tests / max(1, l.rays):.2f} | per wave: inner {l.wave_iters_inner / max(1, l.waves):.1f}"
                  f" leaf {l.wave_iters_leaf / max(1, l.waves):.1f} reject {l.wave_iters_reject / max(1, l.waves):.1f}"
                  f" | lanes busy: node steps {l.node_visits / max(1, 64 * l.wave_iters_inner):.2f} triangle tests {l.tri_tests / max(1, 64 * l.wave_iters_leaf):.2f}") if a.count else ""

@@ -682,6 +682,21 @@ extern "C" int rt_debug_stamps(unsigned long long* out, int reset) {
 }
 #endif
 
+#ifdef RT_DEBUG_HIST
+// Diagnostic build only (-DRT_DEBUG_HIST): how well what is known about a queued hit predicts the cost
+// of the ray scattered from it. [object of the hit, clipped to 7][node visits of the ray that found
+// it, clipped to 63][node visits of the scattered ray, clipped to 63], over the launches over the queue.
+__device__ unsigned long long g_hist[8][64][64];
+extern "C" int rt_debug_hist(unsigned long long* out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hist), sizeof(unsigned long long) * 8 * 64 * 64) != hipSuccess) return RT_ERR_HIP;
+  if (reset) {
+    static unsigned long long zero[8 * 64 * 64];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_hist), zero, sizeof zero) != hipSuccess) return RT_ERR_HIP;
+  }
+  return RT_OK;
+}
+#endif
+
 __device__ __forceinline__ uint32_t linear_block() { return blockIdx.y * gridDim.x + blockIdx.x; }
 
 // The counter line a wave adds to.
@@ -1223,6 +1238,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
   int depth = 0;
   d3 o = mk(0, 0, 0), dir = mk(0, 0, 0), thr = mk(1, 1, 1), rad = mk(0, 0, 0);
   uint32_t fuse_left = STAGE == 0 ? pp.fuse_bounces : 0u;
+#ifdef RT_DEBUG_HIST
+  int32_t dbg_prev = 0, dbg_obj = 0;
+#endif
 
   if (alive) {
     if (STAGE == 0) {
@@ -1244,6 +1262,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
       si.u = r->u;
       si.v = r->v;
       const int32_t id = r->id;
+#ifdef RT_DEBUG_HIST
+      dbg_prev = r->pad;
+      dbg_obj = id >= 0 ? sc.shade[id].obj : sc.spheres[~id].obj;
+#endif
       si.slot = id >= 0 ? id : -1;
       si.sphere = id >= 0 ? -1 : ~id;
       if (COUNT) wc.shaded++;
@@ -1294,6 +1316,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
         depth = __float_as_int(p6.z) + 1;
         if (EMIT) rad = mk(in.rad[entry * 3], in.rad[entry * 3 + 1], in.rad[entry * 3 + 2]);
       }
+#ifdef RT_DEBUG_HIST
+      if (STAGE == 1) atomicAdd(&g_hist[min(max(dbg_obj, 0), 7)][min(max(dbg_prev, 0), 63)][min(steps, 63)], 1ull);
+#endif
       wc.rays++;
       finish_hit<COUNT>(sc, t, h, wc);
       if (!(h.slot >= 0 || h.sphere >= 0)) {

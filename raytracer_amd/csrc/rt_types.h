@@ -30,7 +30,9 @@
 #define RT_LEAF_MAX (1 << RT_LEAF_BITS) /* triangles per leaf                                 */
 #define RT_BVH_MAX_DEPTH 62           /* builder guarantee; the traversal stack is sized by it */
 #define RT_REF_SENTINEL INT32_MIN     /* bottom of the traversal stack / empty tree          */
+#ifndef RT_REJECT_CAP
 #define RT_REJECT_CAP 64              /* tries per rejection loop before the fallback        */
+#endif
 #define RT_TREE_SPHERES 64            /* spheres that can have a place in the tree (one bit each in a ray's candidate mask) */
 
 // A child ref >= 0 is the index of an interior node. A ref < 0 other than RT_REF_SENTINEL is a

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where a wave's lifetime goes, by code section and kernel stage: renders frames of a workload
-with the diagnostic build of the library (-DRT_STAMPS, exp_build/build_variant.sh stamps
+with the diagnostic build of the library (-DRT_STAMPS, tools/experiments/build_variant.sh stamps
 -DRT_STAMPS; RT_AMD_LIB names it) and prints the cycle shares its kernels accumulated.
 
     RT_AMD_LIB=exp_build/librt_stamps.so python tools/stamps.py --workload spot_4k_256spp

@@ -72,6 +72,7 @@ struct LogRec {
 #define RT_PLAN_RECS 4 /* PlanRec per plan slot: [0] the launch, [1] only if it fits `split_at`, [2] only if not */
 #define RT_PLAN_SLOTS 4096  /* ring of plans and counter snapshots; harvested long before it wraps */
 #define RT_LAUNCH_KEEP 4096 /* launch log entries kept one by one; older ones are folded per kind */
+#define RT_EVENT_POOL_FIRST 4096 /* timing events made by a scene's first call with RT_FLAG_TIMING */
 
 struct DeviceScene {
   int device = -1;
@@ -1699,6 +1700,12 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
   const TileMap tm = make_tilemap(p);
   if (tm.n_tiles == 0) return RT_OK;
   const bool timing = (p->flags & RT_FLAG_TIMING) != 0 && !arena;  // timing takes events from a growing pool
+  if (timing && d->ev_pool.size() < RT_EVENT_POOL_FIRST) {
+    // the first timed call of a scene makes the events of a long pipelined run at once (a run of
+    // forty 1080p frames brackets about a thousand launches), so that the calls after it create none
+    hipEvent_t e;
+    if ((rc = event_at(d, RT_EVENT_POOL_FIRST - 1, &e)) != RT_OK) return rc;
+  }
   const bool count = (p->flags & RT_FLAG_COUNT_WORK) != 0;
   const bool regen = (p->flags & RT_FLAG_NO_REGEN) == 0;
   const bool emission = d->k.has_emission != 0;

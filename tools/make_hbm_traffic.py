@@ -42,9 +42,9 @@ merged = {}
 for name, c in pmc.items():
     if not isinstance(c, dict) or not name.startswith("k_") or "<true" in name or any(k not in c for k in need):
         continue
-    # k_wave<COUNT, STAGE, LOOP, QUANT>: the launches of one stage are one entry, whichever nodes they walk
+    # k_wave<COUNT, STAGE, LOOP, QUANT, EMIT, DEEP>: the launches of one stage are one entry, whichever form they run in
     flat_name = name.replace(" ", "")
-    mw = re.match(r"^(k_wave<false,\d+),(false|true)(?:,(?:false|true))?>$", flat_name)
+    mw = re.match(r"^(k_wave<false,\d+),(false|true)(?:,(?:false|true))*>$", flat_name)
     key = mw.group(1) + ">" if mw else flat_name
     # the looping variant is queued behind the plain one as part of the same logged launch: its
     # counts are added, the number of launches is the plain variant's

@@ -51,6 +51,7 @@ using namespace rtk;
 #endif
 #define RT_LEAVE_DEFAULT 32      /* of 64: share of a wave's traversing lanes below which node steps pause for the leaves (trav_run) */
 #define RT_LONG_STEPS_DEFAULT 8u /* node visits from which a ray counts as long (see k_wave) */
+#define RT_GRID_FIRST_MIB 32      /* binary32 node array from which the first stage walks the 16-bit copy too */
 #define RT_DEEP_FROM 40          /* stack entries (tree depth + 2) from which the kernels' DEEP form runs (trav_run) */
 // words of a line
 enum { CNT_RAYS = 0, CNT_NODES, CNT_TRIS, CNT_SPHERES, CNT_SHADED, CNT_PATHS, CNT_Q0, CNT_R0, CNT_Q1, CNT_R1, CNT_WORK, CNT_WI_INNER, CNT_WI_LEAF, CNT_WI_REJECT, CNT_WAVES, CNT_N };
@@ -81,6 +82,11 @@ struct DeviceScene {
   uint64_t bytes = 0;
   uint32_t stack_entries = 2;
   bool grid_ok = false;  // the launches over the queue walk qnodes (else nodes, like everything else)
+  // The first stage walks qnodes too when the tree is far larger than the caches: its coherent rays are
+  // bound by instruction issue, where the twelve conversions a visit cost more than the halved
+  // fetches save (ogre 4K first stage 183.4 -> 190.4 ms, Spot 4K 137.7 -> 140.0), until the nodes
+  // come from HBM (14x14 grid of Spot meshes, 147 MB of binary32 nodes: 32.4 -> 30.8 ms).
+  bool grid_first = false;
   // work buffers, grown on demand
   double* samples = nullptr;
   size_t samples_bytes = 0;
@@ -336,6 +342,9 @@ int rt_device_scene_upload_from(const rt_scene* s, rt_scene* target, int device)
     const char* no_grid = std::getenv("RT_NO_GRID");
     if (no_grid && *no_grid && *no_grid != '0') d->grid_ok = false;
     if (d->grid_ok && (rc = upload_array(d, qn.data(), qn.size(), &d->k.qnodes)) != RT_OK) return fail(rc);
+    d->grid_first = d->grid_ok && s->nodes.size() * sizeof(BvhNode) > ((size_t)RT_GRID_FIRST_MIB << 20);
+    const char* qf = std::getenv("RT_QUANT_FIRST");  // 0 / 1 forces the choice (A/B)
+    if (qf && *qf) d->grid_first = d->grid_ok && *qf != '0';
   }
   if ((rc = upload_array(d, s->tri_geom.data(), s->tri_geom.size(), &d->k.geom)) != RT_OK) return fail(rc);
   if ((rc = upload_array(d, s->tri_shade.data(), s->tri_shade.size(), &d->k.shade)) != RT_OK) return fail(rc);
@@ -1626,7 +1635,7 @@ template <int STAGE>
 static void launch_wave(bool count, bool loop, bool quant, dim3 grid, size_t lds, hipStream_t st, const SceneK& k, const PathParams& pp, const QueueView& in,
                         const QueueView& out, uint32_t n_seg, const PlanRec* plan, uint32_t vb_base, double* samples, unsigned long long* counters) {
 #define RT_LAUNCH_AS(C, L, Q) launch_wave_as<C, STAGE, L, Q>(grid, lds, st, k, pp, in, out, n_seg, plan, vb_base, samples, counters)
-  if constexpr (STAGE == 1) {
+  if constexpr (STAGE == 1 || STAGE == 0) {
     if (quant) {
       if (!loop) {
         if (count) RT_LAUNCH_AS(true, false, true);
@@ -1925,7 +1934,7 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
       HIP_TRY(hipMemset2DAsync(counters + CNT_Q0, line_bytes, 0, 4 * sizeof(unsigned long long), RT_SHARDS, stream));
       if ((rc = begin_launch(0, pp.n_paths, stream)) != RT_OK) return rc;
       // the written-out form for one fused bounce (the default), the looping form for any other number
-      launch_wave<0>(count, fuse_bounces != 1u, false, dim3(blocks_all), lds, stream, d->k, pp, qv[0], qv[0], n_seg, nullptr, 0u, samples, counters);
+      launch_wave<0>(count, fuse_bounces != 1u, d->grid_first, dim3(blocks_all), lds, stream, d->k, pp, qv[0], qv[0], n_seg, nullptr, 0u, samples, counters);
       if ((rc = end_launch(stream)) != RT_OK) return rc;
       // the split of the plan (gather into the tail segment, or tail in place) only matters to the
       // launches after the last bounce, and costs nothing on the others

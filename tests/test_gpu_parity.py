@@ -326,6 +326,13 @@ def test_grid_nodes_and_binary32_nodes_give_the_same_bits(gpu_scenes, oracle, mo
     assert s2.render(c, rt.render_params(width=w, height=h, spp=spp, seed=5)) == rays
     assert c.tobytes() == base.tobytes()
     monkeypatch.delenv("RT_NO_GRID")
+    # the first stage walks the grid copy only for trees far larger than the caches (RT_QUANT_FIRST=1 forces it)
+    monkeypatch.setenv("RT_QUANT_FIRST", "1")
+    s3 = scenes.build("spot")
+    c = np.zeros((h, w, 3))
+    assert s3.render(c, rt.render_params(width=w, height=h, spp=spp, seed=5)) == rays
+    assert c.tobytes() == base.tobytes()
+    monkeypatch.delenv("RT_QUANT_FIRST")
 
     args = _moved("spot", scale=0.15, about=(0.0, 0.0, -3.0), drop_objects=(0,))
     small = rt.Scene.from_desc(*args)

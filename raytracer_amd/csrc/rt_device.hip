@@ -745,15 +745,18 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
   return v;
 }
 
+// WAVE_TOTALS: wc.rays and n_done are the wave's totals already (the same value in every lane:
+// k_wave counts them with ballots, which keeps two registers free), else per-lane counts.
+template <bool WAVE_TOTALS = false>
 __device__ __forceinline__ void flush_counts(const WorkCount& wc, unsigned long long* counters, bool count_all, uint32_t n_done,
                                              uint32_t n_waves = 1) {
   // one atomic per wave and counter, on the wave's own line
   unsigned long long* line = my_line(counters);
-  const unsigned long long r = wave_sum(wc.rays);
+  const unsigned long long r = WAVE_TOTALS ? (unsigned long long)wc.rays : wave_sum(wc.rays);
   if ((threadIdx.x & 63) == 0 && r) atomicAdd(&line[CNT_RAYS], r);
   if (count_all) {
     const unsigned long long a = wave_sum(wc.nodes), b = wave_sum(wc.tris), c = wave_sum(wc.spheres), e = wave_sum(wc.shaded),
-                             f = wave_sum(n_done);
+                             f = WAVE_TOTALS ? (unsigned long long)n_done : wave_sum(n_done);
     if ((threadIdx.x & 63) == 0) {
       if (a) atomicAdd(&line[CNT_NODES], a);
       if (b) atomicAdd(&line[CNT_TRIS], b);
@@ -1248,6 +1251,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
   int depth = 0;
   d3 o = mk(0, 0, 0), dir = mk(0, 0, 0), thr = mk(1, 1, 1), rad = mk(0, 0, 0);
   uint32_t fuse_left = STAGE == 0 ? pp.fuse_bounces : 0u;
+  bool ended = false;  // this lane's path has just ended
 #ifdef RT_DEBUG_HIST
   int32_t dbg_prev = 0, dbg_obj = 0;
 #endif
@@ -1284,7 +1288,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
       if (depth > pp.max_depth) {  // src/main.rs:818
         store_sample(samples, pp.n_paths, path, rad);
         alive = false;
-        n_done++;
+        ended = true;
       }
       // What the walk through the tree does not need waits in the record the lane has just read (the
       // throughput, which shading has changed, is written over the old one; key, path and depth are
@@ -1302,11 +1306,15 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
     }
   }
 
+  n_done += (uint32_t)__popcll(__ballot(ended));  // paths ended and rays cast are counted per wave, not per lane: two registers fewer
+  ended = false;
+
   HitK h;
   h.slot = -1;
   h.sphere = -1;
   int32_t steps = 0;  // node visits of the ray that found this lane's hit
   auto trace = [&]() {
+    wc.rays += (uint32_t)__popcll(__ballot(alive));
     if (alive) {
       Trav t;
       // The launches over the queue walk the half-size copy of the tree (see BvhNodeQ): they are
@@ -1317,6 +1325,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
       steps = t.steps;
       if (STAGE == 1) {
         asm volatile("" ::: "memory");  // the values parked before the walk are read again, not kept
+        // and the record's place is worked out again from the lane index (the old value would hold two registers across the walk)
+        uint32_t lane_again;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(lane_again) : "v"(threadIdx.x));
+        const uint32_t i_again = (vb - (ray_block ? hit_blocks : 0u)) * RT_BLOCK + lane_again;
+        const size_t entry = (size_t)seg * in.seg_cap + (ray_block ? in.seg_cap - 1u - i_again : i_again);
         const double2 p3 = reinterpret_cast<const double2*>(in.recs)[(size_t)3 * in.entries + entry];
         const double2 p4 = reinterpret_cast<const double2*>(in.recs)[(size_t)4 * in.entries + entry];
         const float4 p5 = in.recs[(size_t)5 * in.entries + entry], p6 = in.recs[(size_t)6 * in.entries + entry];
@@ -1329,16 +1342,17 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
 #ifdef RT_DEBUG_HIST
       if (STAGE == 1) atomicAdd(&g_hist[min(max(dbg_obj, 0), 7)][min(max(dbg_prev, 0), 63)][min(steps, 63)], 1ull);
 #endif
-      wc.rays++;
       finish_hit<COUNT>(sc, t, h, wc);
       if (!(h.slot >= 0 || h.sphere >= 0)) {
         const d3 s = sky(sc, dir);  // src/main.rs:826
         rad = rad + mk(thr.x * s.x, thr.y * s.y, thr.z * s.z);
         store_sample(samples, pp.n_paths, path, rad);
         alive = false;
-        n_done++;
+        ended = true;
       }
     }
+    n_done += (uint32_t)__popcll(__ballot(ended));
+    ended = false;
   };
   // from a trace on `alive` means: has a hit waiting to be shaded
   auto shade = [&]() {
@@ -1350,9 +1364,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
       if (depth > pp.max_depth) {
         store_sample(samples, pp.n_paths, path, rad);
         alive = false;
-        n_done++;
+        ended = true;
       }
     }
+    n_done += (uint32_t)__popcll(__ballot(ended));
+    ended = false;
   };
   if (STAGE == 0 && !LOOP) {
     // The first stage following exactly one bounce, written out: camera ray, shade, scattered ray.
@@ -1419,7 +1435,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
   }
   if (!LOOP || STAGE == 0) break;  // the first stage has one block of paths per workgroup
   }  // record blocks of this workgroup
-  flush_counts(wc, counters, COUNT, n_done, n_vb);
+  flush_counts<true>(wc, counters, COUNT, n_done, n_vb);
 #ifdef RT_STAMPS
   RT_ACC(wc, 7);
   if (lane == 0)

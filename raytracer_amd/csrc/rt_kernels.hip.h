@@ -250,8 +250,9 @@ struct Trav {
   float mx_lo, mx_hi, my_lo, my_hi, mz_lo, mz_hi;   // -(o -+ pad) * reciprocal direction
   float best32k;                                    // pruning distance for the f32 box tests
   double best_t, best_u, best_v;
-  int32_t best_slot, best_flat;
+  int32_t best_slot;
   int32_t cur;   // next node/leaf ref, RT_REF_SENTINEL when the traversal has finished
+  uint32_t sel;                                     // grid nodes: per axis (one byte each) the rotation, 0 or 16 bits, that puts the nearer plane into the low half (trav_set_ray)
   int32_t* sp;   // top of the stack column (entries are `stride` ints apart)
   int32_t* base; // bottom of the stack column
   int32_t steps; // interior nodes this ray has visited
@@ -297,6 +298,17 @@ __device__ __forceinline__ void trav_set_ray(Trav& t, const SceneK& sc, const d3
     t.ix *= sc.q_step[0];
     t.iy *= sc.q_step[1];
     t.iz *= sc.q_step[2];
+    // A grid node keeps the two planes of a child on an axis in the halves of one word, min below
+    // max. Which of them the ray meets first is the sign of its direction on that axis, the same at
+    // every node: a rotation by 0 or 16 bits per axis swaps the halves for a negative direction, so that the
+    // low half always holds the nearer plane, and the padded origin terms are swapped with them.
+    // The distances are those the unordered form takes the smaller and the larger of (the padded
+    // box has its min plane below its max plane), without the twelve min/max per visit.
+    t.sel = (t.ix < 0.0f ? 16u : 0u) | (t.iy < 0.0f ? 16u << 8 : 0u) | (t.iz < 0.0f ? 16u << 16 : 0u);
+    // after this, m*_hi goes with the low half (the nearer plane), m*_lo with the high half
+    if (t.ix < 0.0f) { const float a = t.mx_lo; t.mx_lo = t.mx_hi; t.mx_hi = a; }
+    if (t.iy < 0.0f) { const float a = t.my_lo; t.my_lo = t.my_hi; t.my_hi = a; }
+    if (t.iz < 0.0f) { const float a = t.mz_lo; t.mz_lo = t.mz_hi; t.mz_hi = a; }
   }
 }
 
@@ -308,7 +320,6 @@ __device__ __forceinline__ void trav_begin(Trav& t, const SceneK& sc, const d3 o
   t.best_u = 0.0;
   t.best_v = 0.0;
   t.best_slot = -1;
-  t.best_flat = 0x7fffffff;
   t.sp = stk;
   t.base = stk;
   *t.sp = RT_REF_SENTINEL;
@@ -331,9 +342,10 @@ __device__ __forceinline__ void trav_run(Trav& t, const SceneK& sc, const int st
   const d3 o = t.o, d = t.d;
   const float ix = t.ix, iy = t.iy, iz = t.iz;
   const float mx_lo = t.mx_lo, mx_hi = t.mx_hi, my_lo = t.my_lo, my_hi = t.my_hi, mz_lo = t.mz_lo, mz_hi = t.mz_hi;
+  const uint32_t sel = t.sel;
   float best32k = t.best32k;
   double best_t = t.best_t, best_u = t.best_u, best_v = t.best_v;
-  int32_t best_slot = t.best_slot, best_flat = t.best_flat;
+  int32_t best_slot = t.best_slot;
   int32_t cur = t.cur;
   int32_t* sp = t.sp;
   // DEEP: the first RT_DEEP_LDS stack entries in LDS, deeper ones in the lane's private memory.
@@ -369,7 +381,15 @@ __device__ __forceinline__ void trav_run(Trav& t, const SceneK& sc, const int st
       if (QUANT) {
         // a 32-bit byte offset from the (uniform) base: one shift per lane instead of 64-bit address arithmetic
         const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.qnodes) + ((uint32_t)cur << 5));
-        const uint4 w0 = np[0], w1 = np[1];
+        uint4 w0 = np[0], w1 = np[1];
+        // nearer plane into the low half of every word (see trav_set_ray); the rotation takes the low five bits of its operand
+        const uint32_t sel_x = sel, sel_y = sel >> 8, sel_z = sel >> 16;
+        w0.x = __builtin_amdgcn_alignbit(w0.x, w0.x, sel_x);
+        w0.y = __builtin_amdgcn_alignbit(w0.y, w0.y, sel_x);
+        w0.z = __builtin_amdgcn_alignbit(w0.z, w0.z, sel_y);
+        w0.w = __builtin_amdgcn_alignbit(w0.w, w0.w, sel_y);
+        w1.x = __builtin_amdgcn_alignbit(w1.x, w1.x, sel_z);
+        w1.y = __builtin_amdgcn_alignbit(w1.y, w1.y, sel_z);
         bx = make_float4((float)(w0.x & 0xffffu), (float)(w0.x >> 16), (float)(w0.y & 0xffffu), (float)(w0.y >> 16));
         by = make_float4((float)(w0.z & 0xffffu), (float)(w0.z >> 16), (float)(w0.w & 0xffffu), (float)(w0.w >> 16));
         bz = make_float4((float)(w1.x & 0xffffu), (float)(w1.x >> 16), (float)(w1.y & 0xffffu), (float)(w1.y >> 16));
@@ -395,16 +415,24 @@ __device__ __forceinline__ void trav_run(Trav& t, const SceneK& sc, const int st
       const f2 y1 = pk_fma(mk2(by.z, by.w), mk2(iy, iy), mk2(my_hi, my_lo));
       const f2 z1 = pk_fma(mk2(bz.z, bz.w), mk2(iz, iz), mk2(mz_hi, mz_lo));
       float tn0, tf0, tn1, tf1;
-      // child 0
-      tn0 = fmaxf(fminf(x0.x, x0.y), fminf(y0.x, y0.y));
-      tf0 = fminf(fmaxf(x0.x, x0.y), fmaxf(y0.x, y0.y));
-      tn0 = fmaxf(fmaxf(tn0, fminf(z0.x, z0.y)), 0.0f);
-      tf0 = fminf(tf0, fmaxf(z0.x, z0.y));
-      // child 1
-      tn1 = fmaxf(fminf(x1.x, x1.y), fminf(y1.x, y1.y));
-      tf1 = fminf(fmaxf(x1.x, x1.y), fmaxf(y1.x, y1.y));
-      tn1 = fmaxf(fmaxf(tn1, fminf(z1.x, z1.y)), 0.0f);
-      tf1 = fminf(tf1, fmaxf(z1.x, z1.y));
+      if (QUANT) {
+        // .x is the distance to the nearer plane of the axis, .y to the farther one
+        tn0 = fmaxf(fmaxf(fmaxf(x0.x, y0.x), z0.x), 0.0f);
+        tf0 = fminf(fminf(x0.y, y0.y), z0.y);
+        tn1 = fmaxf(fmaxf(fmaxf(x1.x, y1.x), z1.x), 0.0f);
+        tf1 = fminf(fminf(x1.y, y1.y), z1.y);
+      } else {
+        // child 0
+        tn0 = fmaxf(fminf(x0.x, x0.y), fminf(y0.x, y0.y));
+        tf0 = fminf(fmaxf(x0.x, x0.y), fmaxf(y0.x, y0.y));
+        tn0 = fmaxf(fmaxf(tn0, fminf(z0.x, z0.y)), 0.0f);
+        tf0 = fminf(tf0, fmaxf(z0.x, z0.y));
+        // child 1
+        tn1 = fmaxf(fminf(x1.x, x1.y), fminf(y1.x, y1.y));
+        tf1 = fminf(fmaxf(x1.x, x1.y), fmaxf(y1.x, y1.y));
+        tn1 = fmaxf(fmaxf(tn1, fminf(z1.x, z1.y)), 0.0f);
+        tf1 = fminf(tf1, fmaxf(z1.x, z1.y));
+      }
       const f2 tf = mk2(tf0, tf1) * mk2(RT_K_FAR, RT_K_FAR);
       tf0 = tf.x;
       tf1 = tf.y;
@@ -454,13 +482,19 @@ __device__ __forceinline__ void trav_run(Trav& t, const SceneK& sc, const int st
       ok = ok && !(v < 0.0 || u + v > 1.0);
       const double dist = dot(a_to_c, v_vec) * inv_det;
       ok = ok && (dist > eps);
-      // src/main.rs:791: strict <, so of equal distances the first in flat order wins
-      if (ok && (dist < best_t || (dist == best_t && flat < best_flat))) {
+      // src/main.rs:791: strict <, so of equal distances the first in flat order wins. The flat index
+      // of the best hit so far is read again from its record in the rare case of a tie (a register
+      // fewer where the kernels hold most).
+      bool better = ok && dist < best_t;
+      if (ok && dist == best_t) {
+        const int32_t best_flat = reinterpret_cast<const TriGeom*>(reinterpret_cast<const char*>(sc.geom) + (uint32_t)best_slot * (uint32_t)sizeof(TriGeom))->flat;
+        better = flat < best_flat;
+      }
+      if (better) {
         best_t = dist;
         best_u = u;
         best_v = v;
         best_slot = (int32_t)(first + i);
-        best_flat = flat;
         best32k = f32_up(dist) * RT_K_FAR;
       }
     }
@@ -474,7 +508,6 @@ __device__ __forceinline__ void trav_run(Trav& t, const SceneK& sc, const int st
   t.best_u = best_u;
   t.best_v = best_v;
   t.best_slot = best_slot;
-  t.best_flat = best_flat;
   t.cur = cur;
   t.sp = sp;
   t.steps = steps;

@@ -351,10 +351,11 @@ int rt_render_accumulate(rt_scene* scene, const rt_render_params* p, double* can
  * for the default stream); returns without waiting. The scene remembers the stream (later calls
  * and rt_scene_wait synchronise with it: a call on another stream starts behind what the previous
  * call queued), so it must outlive the scene's next call.
- * The sizes of the launches over the ray queue are decided on the device; the first frame of a
- * new shape (image size, samples, tile split, depth cap) is the exception: there the host waits
- * for the queue counts between launches to learn how many launches such a frame takes. Callers
- * that must not block (graph capture) render one frame of the shape beforehand. */
+ * The sizes of the launches over the ray queue are decided on the device, so the call waits for
+ * nothing, on any frame: a frame of a shape (image size, samples, tile split, depth cap) the scene
+ * has rendered before is queued with the launches that frame needed, a frame of a new shape with
+ * launches that cover a queue of any length (slower; it is one frame). A frame can therefore be
+ * captured into a HIP graph from the first call on. */
 int rt_render_device(rt_scene* scene, const rt_render_params* p, double* device_canvas, void* stream);
 
 /* No counterpart in the reference. rt_render_device for callers that cannot allocate (code under

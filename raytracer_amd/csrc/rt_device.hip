@@ -115,7 +115,7 @@ struct DeviceScene {
   unsigned long long base_main[CNT_N] = {};  // the latest snapshots' sums, kept across a harvest (their slots may be reused)
   unsigned long long base_tail[CNT_N] = {};
   // How many bounce launches a frame of a given shape needed before its queue was down to the
-  // tail threshold: learnt on the first such frame (the host watches the counts), then reused, so
+  // tail threshold: learnt from the plans the first such frame leaves behind, then reused, so
   // that later frames are queued without the host waiting for anything.
   struct Hist {
     uint64_t key = 0;
@@ -390,6 +390,8 @@ int rt_device_scene_upload_from(const rt_scene* s, rt_scene* target, int device)
     // RT_DEEP_STACK=0/1 forces the choice (A/B)
     const char* e = std::getenv("RT_DEEP_STACK");
     d->k.deep_stack = e && *e ? (*e != '0' && d->stack_entries > (uint32_t)RT_DEEP_LDS ? 1u : 0u) : (d->stack_entries >= (uint32_t)RT_DEEP_FROM ? 1u : 0u);
+    // the same form of the kernels is the one that handles spheres with places in the tree
+    if (d->k.sph_places) d->k.deep_stack = 1u;
   }
   if (hipMalloc((void**)&d->counters, RT_COUNTER_BYTES) != hipSuccess) {
     rt_set_error("rt_scene_upload: hipMalloc of the counters failed");
@@ -1342,7 +1344,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wave(SceneK sc, PathParams pp, Que
 #ifdef RT_DEBUG_HIST
       if (STAGE == 1) atomicAdd(&g_hist[min(max(dbg_obj, 0), 7)][min(max(dbg_prev, 0), 63)][min(steps, 63)], 1ull);
 #endif
-      finish_hit<COUNT>(sc, t, h, wc);
+      finish_hit<COUNT, DEEP>(sc, t, h, wc);
       if (!(h.slot >= 0 || h.sphere >= 0)) {
         const d3 s = sky(sc, dir);  // src/main.rs:826
         rad = rad + mk(thr.x * s.x, thr.y * s.y, thr.z * s.z);
@@ -1837,7 +1839,7 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
   if (long_steps == 0) long_steps = 0x7fffffffu;
   // RT_GRID_BLOCKS: workgroups of the looping form of a launch over a queue
   const uint32_t grid_blocks = (uint32_t)env_mib("RT_GRID_BLOCKS", 4096);
-  // RT_SYNC_ROUNDS=1: the host watches the queue counts of every frame (as on a frame of a new shape)
+  // RT_SYNC_ROUNDS=1: the host reads every plan of every frame before the launch it sizes (a wait per bounce; A/B)
   const char* sync_env = std::getenv("RT_SYNC_ROUNDS");
   const bool always_watch = sync_env && *sync_env && *sync_env != '0';
   int cus = 256;
@@ -1959,7 +1961,7 @@ static int render_impl(rt_scene* s, const rt_render_params* p, double* d_canvas,
       account_main(snap, -1);
 
       // Bounce launches. A frame of a shape seen before is queued blind, with as many launches as
-      // that frame needed; on a new shape the host waits for each plan and stops at the threshold.
+      // that frame needed; a frame of a new shape with a guessed number of launches in the looping form.
       uint64_t key = 0xcbf29ce484222325ull;
       for (uint64_t v : {(uint64_t)pp.n_paths, (uint64_t)pp.spp, (uint64_t)p->width, (uint64_t)p->height, (uint64_t)(uint32_t)p->max_depth,
                          (uint64_t)p->tile_size, (uint64_t)p->tile_rank, (uint64_t)p->tile_ranks, (uint64_t)fuse_bounces, (uint64_t)long_steps,

@@ -329,6 +329,9 @@ __device__ __forceinline__ void trav_begin(Trav& t, const SceneK& sc, const d3 o
 }
 
 // Runs the traversal to its end (t.cur == RT_REF_SENTINEL).
+// DEEP is the kernels' general form: it is also the one that knows about spheres with places in
+// the tree (scenes of nine spheres or more), so that the form every other scene runs carries neither
+// (1-1.5 % of a frame).
 // The stack is a full stack in LDS, sized from the tree's depth: up to 39 entries (10 KB a wave)
 // that costs a kernel of five waves per SIMD nothing. DEEP, for the trees beyond (the builders stop
 // at RT_BVH_MAX_DEPTH; only bottom-up clustering of a soup of overlapping triangles gets there):
@@ -468,7 +471,7 @@ __device__ __forceinline__ void trav_run(Trav& t, const SceneK& sc, const int st
       const int32_t flat = g->flat;
       if (COUNT) wc.tris++;
       // a sphere's place in the tree (all-zero geometry: the test below fails by itself): note the sphere
-      if (sc.sph_places && flat < 0) spheres |= 1ull << ((uint32_t)~flat & 63u);
+      if (DEEP && sc.sph_places && flat < 0) spheres |= 1ull << ((uint32_t)~flat & 63u);
       // intersects_triangle, src/main.rs:187-239
       const d3 u_vec = cross(d, a_to_c);
       const double det = dot(a_to_b, u_vec);
@@ -547,7 +550,9 @@ __device__ __forceinline__ void test_sphere(const SceneK& sc, uint32_t i, const 
 // place the ray reached (t.spheres) are tested — a ray cannot hit a sphere without entering its
 // box. Spheres without a place (not finite, or beyond the 64 the mask has bits for:
 // sc.sph_always and the indices from 64 on) are tested always.
-template <bool COUNT>
+// PLACES: the scene's spheres may have places in the tree (the kernels' DEEP form, which is also the
+// form for scenes with such places: see trav_run); without it every sphere is tested against every ray.
+template <bool COUNT, bool PLACES = false>
 __device__ __forceinline__ void finish_hit(const SceneK& sc, const Trav& t, HitK& h, WorkCount& wc) {
   const d3 o = t.o, d = t.d;
   h.t = t.best_t;
@@ -557,11 +562,15 @@ __device__ __forceinline__ void finish_hit(const SceneK& sc, const Trav& t, HitK
   h.sphere = -1;
   // (a) the spheres every ray tests: the same index in every lane, so the record is read once per
   // wave into scalar registers
-  const uint32_t n_low = min(sc.n_spheres, (uint32_t)RT_TREE_SPHERES);
+  const uint32_t n_low = PLACES ? min(sc.n_spheres, (uint32_t)RT_TREE_SPHERES) : sc.n_spheres;
   for (uint32_t i = 0; i < n_low; ++i) {
-    if (!((sc.sph_always >> i) & 1ull)) continue;
+    if (PLACES && !((sc.sph_always >> i) & 1ull)) continue;
     if (COUNT) wc.spheres++;
     test_sphere(sc, i, o, d, h);
+  }
+  if (!PLACES) {
+    RT_ACC(wc, 6);
+    return;
   }
   // (b) the spheres whose place this ray reached
   unsigned long long mask = sc.sph_places ? t.spheres : 0ull;
@@ -584,7 +593,7 @@ __device__ __forceinline__ void trace_ray(const SceneK& sc, const d3 o, const d3
   Trav t;
   trav_begin(t, sc, o, d, stk);
   trav_run<COUNT, false, DEEP>(t, sc, stride, wc);
-  finish_hit<COUNT>(sc, t, h, wc);
+  finish_hit<COUNT, DEEP>(sc, t, h, wc);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -13,7 +13,7 @@ for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), 
         c = out.setdefault(name, {})
         c[row["Counter_Name"]] = c.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
 for name in sorted(out):
-    if not name.startswith("k_wave"): continue
+    if not (name.startswith("k_wave") or name.startswith("k_pool")): continue
     c = out[name]; calls, ms = dur.get(name, (0, 0.0))
     w = max(1.0, c.get("SQ_WAVES", 0))
     cyc = ms * 1e-3 * 2.4e9 * 1024  # SIMD-cycles at 2.4 GHz

@@ -301,7 +301,7 @@ def main():
     if rank == 0:
         value = rays_all / elapsed / 1e6
         roofline, kernels = roofline_block(args.workload, timed, counted, cst, per_ray, args.steps, rays_total, scene.export_grid_bvh() is not None,
-                                           torch.cuda.get_device_properties(device))
+                                           torch.cuda.get_device_properties(device), first_on_grid=first_stage_on_grid(scene))
         library_digest = (_ffi.lib.rt_source_digest() or b"unknown").decode()  # digest of the sources the library was built from
         out = {
             "metric": "Mrays/s (primary+secondary)",
@@ -354,7 +354,18 @@ L2_LINE_BYTES = 128.0  # one L2 request moves at most one 128-byte line
 L1_ACCESS_BYTES = 64.0  # one vector-L1 access moves at most 64 bytes
 
 
-def roofline_block(workload, timed, counted, cst, per_ray, steps, rays_total, grid_nodes, prop):
+def first_stage_on_grid(scene):
+    """Whether the first stage walks the 32-byte copy of the nodes too: the library's rule (trees whose
+    binary32 nodes exceed 32 MiB; RT_QUANT_FIRST=0/1 forces the choice) for scenes that have the copy."""
+    if scene.export_grid_bvh() is None:
+        return False
+    forced = os.environ.get("RT_QUANT_FIRST", "")
+    if forced:
+        return forced[0] != "0"
+    return int(scene.info().bvh_nodes) * 64 > (32 << 20)
+
+
+def roofline_block(workload, timed, counted, cst, per_ray, steps, rays_total, grid_nodes, prop, first_on_grid=False):
     """Roofline of the dominant kernel (largest total time among the timed launches) of a run.
 
     Algorithmic work per ray, from that kernel's own per-ray means (counting build of the same
@@ -375,8 +386,9 @@ def roofline_block(workload, timed, counted, cst, per_ray, steps, rays_total, gr
         c_rays, c_nodes, c_tris = cst.rays, cst.node_visits, cst.tri_tests
     if d_rays == 0:
         d_rays = rays_total
-    # only the launches over the queue walk the 32-byte copy of the nodes, and only in scenes that qualify for it
-    node_bytes = 32.0 if (dom == 1 and grid_nodes) else 64.0
+    # the launches over the queue walk the 32-byte copy of the nodes in scenes that qualify for it; the first
+    # stage does so only for trees far larger than the caches (first_on_grid); the tail never
+    node_bytes = 32.0 if grid_nodes and (dom == 1 or (dom == 0 and first_on_grid)) else 64.0
     bytes_per_ray = node_bytes * c_nodes / c_rays + 192.0 * c_tris / c_rays + 88.0
     fetch_bytes_per_ray = node_bytes * c_nodes / c_rays + 80.0 * c_tris / c_rays + 128.0 * per_ray["shaded"] + 88.0
     f32_flops_per_ray = 24.0 * c_nodes / c_rays
